@@ -1,0 +1,236 @@
+/*
+ * rmd_api.h — C ABI of librmd.so, the MI355X (gfx950) filter / SVGF hot path.
+ *
+ * This is the drop-in boundary.  The reference (VictorHerbert/RaymarchDenoiserCuda) has no FFI
+ * layer: its "API" is two __global__ symbols launched with <<<>>> straight from the test TU
+ * (reference include/filter.cuh:25-26, src/test.cu:73-75,85-87).  Host code here stays plain
+ * C/C++ and reaches the HIP kernels only through the extern "C" functions below; every function
+ * names the reference interface it replaces.
+ *
+ * Conventions
+ *   - All functions return 0 on success, a positive hipError_t on a HIP failure, or a negative
+ *     RMD_E_* code on an argument error.  rmd_last_error_string() describes the last failure of
+ *     the calling thread.  (The reference checks nothing: include/vector.h:119-169.)
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.  Launchers are
+ *     asynchronous on that stream.  The library never owns caller planes.
+ *   - float4 planes are passed as `float*` (4 floats per pixel, 16-byte aligned, row-major,
+ *     index y*W+x as in reference include/extended_math.h:66-68); float2 planes as `float*`
+ *     (2 floats per pixel, 8-byte aligned).
+ */
+#ifndef RMD_API_H
+#define RMD_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- error codes (negative = argument errors; positive = hipError_t) ------------------- */
+#define RMD_OK              0
+#define RMD_E_NULL         (-1)  /* a required pointer is NULL                               */
+#define RMD_E_SHAPE        (-2)  /* non-positive width/height, or pixel count overflows int  */
+#define RMD_E_PARAM        (-3)  /* radius<0, depth<1, unknown filter type, bad iteration ...*/
+#define RMD_E_BUFFER       (-4)  /* depth>1 with NULL buffer[], or in/out planes alias       */
+#define RMD_E_ROWS         (-5)  /* row range outside the frame or not covered by the buffer */
+#define RMD_E_UNSUPPORTED  (-6)  /* filter type declared by the reference but not built yet  */
+#define RMD_E_ALIGN        (-7)  /* plane pointer not aligned for its vector type            */
+
+/* ---- PODs mirroring the reference host structs ------------------------------------------ */
+typedef struct rmd_int2   { int x, y; } rmd_int2;
+typedef struct rmd_uchar4 { unsigned char x, y, z, w; } rmd_uchar4;
+
+/* reference include/gbuffer.h:6-14 — 56 bytes, align 8: shape@0 render@8 denoised@16 normal@24
+ * albedo@32 buffer@40.  Passed BY VALUE exactly as the reference passes it in the kernarg. */
+typedef struct rmd_gbuffer {
+    rmd_int2    shape;
+    rmd_uchar4* render;
+    rmd_uchar4* denoised;
+    rmd_uchar4* normal;
+    rmd_uchar4* albedo;
+    rmd_uchar4* buffer[2];
+} rmd_gbuffer;
+
+/* reference include/filter.cuh:11-23 — 36 bytes, align 4: type@0 depth@4 level@8 radius@12
+ * sigmaSpace@16 sigmaColor@20 sigmaAlbedo@24 sigmaNormal@28 cacheInput@32 cacheBuffer@33.
+ * (The reference struct has default member initialisers, so it is not valid C; this is its C
+ * mirror and include/filter.h static_asserts that the two layouts agree.) */
+enum { RMD_FILTER_AVERAGE = 0, RMD_FILTER_GAUSSIAN = 1, RMD_FILTER_CROSS = 2, RMD_FILTER_WAVELET = 3 };
+typedef struct rmd_filter_params {
+    int   type;
+    int   depth;
+    int   level;
+    int   radius;
+    float sigmaSpace;
+    float sigmaColor;
+    float sigmaAlbedo;
+    float sigmaNormal;
+    unsigned char cacheInput;   /* reference default: true */
+    unsigned char cacheBuffer;  /* reference default: true */
+} rmd_filter_params;
+
+/* ---- uchar4 filter launchers (the path the reference actually implements) --------------- */
+
+/* Replaces `filterKernelBaseline<<<grid,block,smem>>>(frame, params)` — reference
+ * src/filter.cu:13-58 as launched at src/test.cu:73-75.  Box mean over the in-bounds taps of a
+ * (2r+1)^2 window, fp32 accumulate, one divide, truncating cast; the output is GRAY from the R
+ * mean (src/filter.cu:51-53).  One launch per level (the reference's single-launch level loop
+ * races across blocks for depth>1).  .w of the output is written as 0. */
+int rmd_filter_baseline(rmd_gbuffer frame, rmd_filter_params params, void* stream);
+
+/* Replaces `filterKernelTiled<<<...>>>(frame, params)` — reference src/filter.cu:87-158 as
+ * launched at src/test.cu:85-87.  Same box mean per RGB channel, .w = 0.  cacheInput=true stages
+ * tile+halo in LDS (the job of reference cacheTile, src/filter.cu:60-85) with a consistent
+ * stride, so both settings give the cacheInput=false result (the reference's cacheInput=true
+ * output is corrupted by a stride mismatch, SURVEY §0.2, and is not a parity target).
+ * params.type selects AVERAGE (reference behaviour) or the declared-but-unimplemented
+ * GAUSSIAN / CROSS / WAVELET modes (include/filter.cuh:12-19); those return
+ * RMD_E_UNSUPPORTED until built. */
+int rmd_filter_tiled(rmd_gbuffer frame, rmd_filter_params params, void* stream);
+
+/* ---- SVGF (north_star hot path; the reference only names it: README.md:3-10) ------------ */
+
+/* Parameters of the three SVGF passes.  Semantics: SURVEY.md Appendix A (normative for this
+ * build).  rmd_svgf_default_params() fills the defaults quoted there. */
+typedef struct rmd_svgf_params {
+    /* T: temporal reprojection + accumulation */
+    float alpha_color;      /* 0.05  minimum blend weight of the new colour sample             */
+    float alpha_moments;    /* 0.2   minimum blend weight of the new luminance moments         */
+    int   h_max;            /* 32    history length clamp                                      */
+    float k_z;              /* 10    depth-consistency slope factor                            */
+    float k_n;              /* 0.9   normal-consistency cosine threshold                       */
+    int   max_motion_rows;  /* 64    history taps with |tap.y - y| > this are invalid; makes the
+                                     result independent of the row-strip decomposition         */
+    /* V: spatial variance fallback */
+    int   var_h_threshold;  /* 4     pixels with history < this use the 7x7 spatial estimate   */
+    int   var_radius;       /* 3     */
+    /* A: edge-stopping a-trous */
+    float sigma_n;          /* 128 */
+    float sigma_z;          /* 1   */
+    float sigma_l;          /* 4   */
+    int   iterations;       /* 5   step 2^i for i in [0, iterations)                           */
+    int   hist_iteration;   /* 0   output of this iteration becomes next frame's hist_color    */
+    int   atrous_variant;   /* 0 auto | 1 direct (global loads) | 2 LDS row-streaming           */
+    int   reserved0;
+    int   reserved1;
+} rmd_svgf_params;
+
+void rmd_svgf_default_params(rmd_svgf_params* p);
+
+/* One frame of SVGF work on one device.  The planes may hold a ROW STRIP of a taller frame:
+ * every plane stores global rows [buf_row0, buf_row0+buf_rows) of a width x height frame, local
+ * row r <-> global row buf_row0+r.  Taps outside the GLOBAL frame are skipped and renormalised
+ * (reference border rule, src/filter.cu:38-39,49); taps inside the global frame must be inside
+ * the buffer (checked on the host, RMD_E_ROWS). */
+typedef struct rmd_svgf_frame_desc {
+    int width, height;        /* global frame */
+    int buf_row0, buf_rows;   /* rows held by every plane below */
+    /* inputs of this frame */
+    const float* color;        /* float4 rgb = noisy illumination, a = unused on input          */
+    const float* nd;           /* float4 (nx,ny,nz, linear z)                                   */
+    const float* motion;       /* float2 pixels, current -> previous                            */
+    /* history (previous frame) */
+    const float* hist_color;   /* float4 rgb + variance                                         */
+    const float* hist_moments; /* float4 (m1, m2, history length, 0)                            */
+    const float* prev_nd;      /* float4                                                        */
+    /* intermediates / outputs */
+    float* t_color;            /* T out: float4 (c', variance)                                  */
+    float* t_moments;          /* T out: float4 (m1', m2', h, 0) -> next frame's hist_moments   */
+    int*   t_debug;            /* optional int4 (q0.x, q0.y, tap mask, h): the bit-exact outputs */
+    float* v_color;            /* V out: float4                                                 */
+    float* hist_color_out;     /* A out of iteration `hist_iteration` -> next frame's hist_color */
+    float* ping[2];            /* A ping-pong planes                                            */
+    float* out_color;          /* A out of the last iteration: denoised illumination + variance */
+    float* stats;              /* optional 4 floats, ACCUMULATED by V with wavefront reductions:
+                                  [0] sum of variance, [1] pixels on the spatial path,
+                                  [2] sum of history length, [3] pixels processed              */
+} rmd_svgf_frame_desc;
+
+/* Pass launchers.  [row0,row1) are GLOBAL output rows. */
+int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);
+int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);
+/* One a-trous iteration (step 2^iteration) from plane `in` to plane `out` (both float4, same
+ * buffer geometry as f; f->nd supplies normals/depth). */
+int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
+                    const float* in, float* out, int row0, int row1, void* stream);
+/* T + V + `iterations` x A for final output rows [row0,row1).  Earlier passes are computed on
+ * the rows later passes tap (redundant rows instead of per-pass halo exchanges);
+ * those rows are clamped to the global frame and must lie inside the buffer. */
+int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);
+/* Rows needed / produced above and below [row0,row1) by rmd_svgf_frame (for sizing buffers and
+ * halo exchanges): reach[0] = current-frame input planes read, reach[1] = history planes read,
+ * reach[2] = rows on which hist_color_out is (redundantly) produced, reach[3] = same for
+ * t_moments.  A strip already holds reach[2]/reach[3] halo rows of its own next-frame history
+ * bit-identical to its neighbour's, so only rows (reach[2], reach[1]] resp. (reach[3], reach[1]]
+ * have to be exchanged. */
+int rmd_svgf_frame_reach(const rmd_svgf_params* p, int reach[4]);
+
+/* Opaque per-device context owning the cross-frame state (history planes are the only state
+ * that outlives a frame; SURVEY §5 "Checkpoint / resume"). */
+typedef struct rmd_svgf_context rmd_svgf_context;
+int  rmd_svgf_context_create(int width, int height, int buf_row0, int buf_rows, rmd_svgf_context** out);
+void rmd_svgf_context_destroy(rmd_svgf_context* ctx);
+int  rmd_svgf_context_reset_history(rmd_svgf_context* ctx, void* stream);
+/* Denoise one frame: borrows color/nd/motion/prev_nd (prev_nd = the nd plane passed for the
+ * previous frame; the caller double-buffers its G-buffer), writes rows [row0,row1) of `out`
+ * (float4, same buffer geometry) and rotates the history planes. */
+int  rmd_svgf_context_denoise(rmd_svgf_context* ctx, const rmd_svgf_params* p,
+                              const float* color, const float* nd, const float* motion,
+                              const float* prev_nd, float* out, int row0, int row1, void* stream);
+/* The history planes the NEXT rmd_svgf_context_denoise call will read (for halo exchange). */
+int  rmd_svgf_context_history(rmd_svgf_context* ctx, float** hist_color, float** hist_moments);
+/* Fill a descriptor with the context's planes for the next frame (advanced use / tests). */
+int  rmd_svgf_context_describe(rmd_svgf_context* ctx, rmd_svgf_frame_desc* f);
+
+/* ---- 8-bit <-> float plane conversion --------------------------------- */
+/* uchar4 -> float4, c/255; optional per-pixel renormalisation of xyz (for normals). */
+int rmd_convert_u8_to_f32(const rmd_uchar4* in, float* out, size_t pixels, int renormalize_xyz, float w_value, void* stream);
+/* float4 illumination (x optional float4 albedo) -> clamp -> uchar4. */
+int rmd_convert_f32_to_u8(const float* in, const float* albedo, rmd_uchar4* out, size_t pixels, void* stream);
+
+/* ---- synthetic G-buffer generator (SURVEY §8d "Synthetic inputs") ------------------------ */
+typedef struct rmd_synth_desc {
+    int      width, height;     /* global frame */
+    int      buf_row0, buf_rows;
+    uint32_t seed;              /* 1234 */
+    int      frame;             /* 0..59 */
+    float    pan_x, pan_y;      /* 1.25, -0.5 px/frame */
+} rmd_synth_desc;
+/* Writes color (float4), nd (float4), motion (float2), albedo (float4, optional) for the
+ * buffer rows; counter-based RNG, so every rank generates identical pixels. */
+int rmd_synth_gbuffer(const rmd_synth_desc* d, float* color, float* nd, float* motion, float* albedo, void* stream);
+
+/* ---- device memory / runtime (replaces reference CudaVector internals, vector.h:119-169) - */
+int  rmd_malloc(void** ptr, size_t bytes);
+int  rmd_free(void* ptr);
+int  rmd_memset(void* ptr, int value, size_t bytes, void* stream);
+int  rmd_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int  rmd_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int  rmd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int  rmd_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream);
+int  rmd_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream);
+int  rmd_host_alloc_pinned(void** ptr, size_t bytes);
+int  rmd_host_free_pinned(void* ptr);
+int  rmd_stream_create(void** stream);
+int  rmd_stream_destroy(void* stream);
+int  rmd_stream_sync(void* stream);
+int  rmd_device_sync(void);              /* reference cudaDeviceSynchronize(), src/test.cu:77,89 */
+int  rmd_device_count(int* count);
+int  rmd_set_device(int device);
+/* reference printGPUProperties(), src/utils.cpp:5-15 */
+int  rmd_print_device_properties(void);
+const char* rmd_last_error_string(void);
+const char* rmd_version(void);
+
+/* HIP-event timing of a region on a stream (bench / harness). */
+int  rmd_timer_create(void** timer);
+int  rmd_timer_destroy(void* timer);
+int  rmd_timer_start(void* timer, void* stream);
+int  rmd_timer_stop(void* timer, void* stream);
+int  rmd_timer_elapsed_ms(void* timer, float* ms); /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMD_API_H */

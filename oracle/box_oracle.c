@@ -1,0 +1,83 @@
+/*
+ * oracle/box_oracle.c — scalar restatement of the reference's uchar4 box filter.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Pinned by SURVEY §8(c) SHA-256 known answers.
+ */
+#include "oracle.h"
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+/* reference src/filter.cu:30-53 (baseline) and :115-155 (tiled): float accumulators start at 0,
+ * taps visited dx-outer / dy-inner (:34-35, :119-120), out-of-range taps skipped (:38-39,
+ * :124-125), w = 1 (:41, :127), norm counts the taps (:46, :146), one division (:49, :148),
+ * truncating float->uchar cast (:51-53, :151-155). */
+void orc_box_level(const uint8_t* in, uint8_t* out, int W, int H, int radius, int gray_from_r,
+                   int row0, int row1)
+{
+    for (int y = row0; y < row1; ++y) {
+        for (int x = 0; x < W; ++x) {
+            float ax = 0.0f, ay = 0.0f, az = 0.0f, norm = 0.0f;
+            for (int dx = -radius; dx <= radius; ++dx) {
+                for (int dy = -radius; dy <= radius; ++dy) {
+                    int nx = x + dx, ny = y + dy;
+                    if (nx < 0 || nx >= W || ny < 0 || ny >= H) continue;
+                    const uint8_t* t = in + ((size_t)ny * W + nx) * 4;
+                    ax += 1.0f * (float)t[0];
+                    ay += 1.0f * (float)t[1];
+                    az += 1.0f * (float)t[2];
+                    norm += 1.0f;
+                }
+            }
+            ax /= norm; ay /= norm; az /= norm;
+            uint8_t* o = out + ((size_t)y * W + x) * 4;
+            if (gray_from_r) {
+                o[0] = o[1] = o[2] = (uint8_t)ax;      /* src/filter.cu:51-53 */
+            } else {
+                o[0] = (uint8_t)ax; o[1] = (uint8_t)ay; o[2] = (uint8_t)az;
+            }
+            o[3] = 0;
+        }
+    }
+}
+
+void orc_box_filter(const uint8_t* render, uint8_t* denoised, uint8_t* buf0, uint8_t* buf1,
+                    int W, int H, int radius, int depth, int gray_from_r)
+{
+    uint8_t* buf[2] = { buf0, buf1 };
+    for (int level = 0; level < depth; ++level) {
+        const uint8_t* in = (level == 0) ? render : buf[level % 2];          /* src/filter.cu:24 */
+        uint8_t* out = (level == depth - 1) ? denoised : buf[(level + 1) % 2]; /* src/filter.cu:25 */
+        orc_box_level(in, out, W, H, radius, gray_from_r, 0, H);
+    }
+}
+
+typedef struct { const uint8_t* in; uint8_t* out; int W, H, radius, gray, row0, row1; } box_job;
+static void* box_worker(void* a) {
+    box_job* j = (box_job*)a;
+    orc_box_level(j->in, j->out, j->W, j->H, j->radius, j->gray, j->row0, j->row1);
+    return NULL;
+}
+
+void orc_box_filter_mt(const uint8_t* render, uint8_t* denoised, int W, int H, int radius,
+                       int gray_from_r, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > H) threads = H;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * threads);
+    box_job* jobs = (box_job*)malloc(sizeof(box_job) * threads);
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (box_job){ render, denoised, W, H, radius, gray_from_r,
+                             (int)((long)H * t / threads), (int)((long)H * (t + 1) / threads) };
+        if (t + 1 < threads) pthread_create(&th[t], NULL, box_worker, &jobs[t]);
+    }
+    box_worker(&jobs[threads - 1]);
+    for (int t = 0; t + 1 < threads; ++t) pthread_join(th[t], NULL);
+    free(th); free(jobs);
+}
+
+int orc_hardware_threads(void)
+{
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    return n > 0 ? (int)n : 1;
+}

@@ -1,0 +1,22 @@
+"""raymarchdenoisercuda_amd — MI355X (gfx950) native filter / SVGF hot path.
+
+Drop-in for the hot path of VictorHerbert/RaymarchDenoiserCuda (include/filter.cuh entry points,
+gbuffer.h / image.h host structs) plus the SVGF passes its README names.  All compute is in the
+hand-written HIP kernels of lib/librmd.so behind the C ABI of include/rmd_api.h; this package is
+the Python host-side mirror used by tests/ and bench.py (the C++ mirror is include/*.h +
+raymarchdenoisercuda_amd/host/).  There is no CPU fallback: importing fails if the library is
+not built.
+"""
+from ._lib import (FilterParams, GBuffer, Int2, LIB_PATH, RmdError, SvgfFrameDesc, SvgfParams, SynthDesc,
+                   check, last_error, lib)
+from .filter import box_filter, filterKernelBaseline, filterKernelTiled, make_gbuffer
+from . import sharding, svgf
+from .svgf import SvgfDenoiser, default_params
+
+__all__ = ["FilterParams", "GBuffer", "Int2", "LIB_PATH", "RmdError", "SvgfFrameDesc", "SvgfParams", "SynthDesc",
+           "check", "last_error", "lib", "box_filter", "filterKernelBaseline", "filterKernelTiled", "make_gbuffer",
+           "sharding", "svgf", "SvgfDenoiser", "default_params"]
+
+
+def version():
+    return lib.rmd_version().decode()

@@ -1,0 +1,86 @@
+// common.h — shared by every TU of librmd.so (host side of the C-ABI shim + device helpers).
+// gfx950 only: wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/rmd_api.h"
+
+namespace rmd {
+
+// ---- error plumbing -----------------------------------------------------------------------
+// The reference checks no CUDA return code (include/vector.h:119-169, src/test.cu:73-89); here
+// every entry point returns an int and records a message for rmd_last_error_string().
+void set_error(const char* fmt, ...);
+int  fail(int code, const char* fmt, ...);          // records message, returns code
+int  hip_fail(hipError_t e, const char* what);      // records "<what>: <hipGetErrorString>"
+
+#define RMD_HIP(call)                                                   \
+    do {                                                                \
+        hipError_t rmd_e_ = (call);                                     \
+        if (rmd_e_ != hipSuccess) return ::rmd::hip_fail(rmd_e_, #call); \
+    } while (0)
+
+#define RMD_LAUNCH_CHECK(name)                                          \
+    do {                                                                \
+        hipError_t rmd_e_ = hipGetLastError();                          \
+        if (rmd_e_ != hipSuccess) return ::rmd::hip_fail(rmd_e_, name); \
+    } while (0)
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kXcds = 8;         // MI355X accelerator complex dies (one L2 each)
+constexpr int kCus  = 256;
+
+// Plane geometry shared by the SVGF kernels: planes hold global rows
+// [buf_row0, buf_row0 + buf_rows) of a W x H frame.
+struct Geom {
+    int W, H, buf_row0, buf_rows;
+};
+
+int check_frame_geometry(const rmd_svgf_frame_desc* f);
+// rows [lo,hi) clamped to the frame must be inside the buffer
+int check_rows_in_buffer(const rmd_svgf_frame_desc* f, int lo, int hi, const char* what);
+
+}  // namespace rmd
+
+// ---- device helpers -------------------------------------------------------------------------
+#if defined(__HIPCC__)
+namespace rmd {
+
+__device__ __forceinline__ size_t pix_index(const Geom& g, int x, int y)
+{
+    return (size_t)(y - g.buf_row0) * (size_t)g.W + (size_t)x;
+}
+
+__device__ __forceinline__ float lum3(float r, float g, float b)
+{
+    // same operation order as the oracle (oracle/svgf_oracle.c lum3), no contraction
+    return 0.2126f * r + 0.7152f * g + 0.0722f * b;
+}
+
+__device__ __forceinline__ bool is_zero3(float4 n) { return n.x == 0.0f && n.y == 0.0f && n.z == 0.0f; }
+
+// v_exp_f32 / v_log_f32 (base 2, 1 ulp): the edge-stopping weights are evaluated in the log2
+// domain, w = exp2(log2 k + sigma_n*log2(max(0,n.n)) - (w_z + w_l)*log2 e)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x)  { return __builtin_amdgcn_rcpf(x); }
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// wave64 butterfly sum (DPP/ds_bpermute under the hood); every lane ends with the total
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace rmd
+#endif

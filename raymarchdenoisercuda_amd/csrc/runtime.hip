@@ -1,0 +1,247 @@
+// runtime.hip — device memory, streams, timers, device properties behind the C ABI.
+// Replaces what the reference does inline through the CUDA runtime: CudaVector's
+// cudaMalloc/cudaMemcpy/cudaFree (reference include/vector.h:119-169),
+// cudaDeviceSynchronize (src/test.cu:77,89) and printGPUProperties (src/utils.cpp:5-15).
+#include "common.h"
+#include <cstring>
+#include <string>
+
+namespace rmd {
+
+static thread_local char g_err[512] = "no error";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+int check_frame_geometry(const rmd_svgf_frame_desc* f)
+{
+    if (!f) return fail(RMD_E_NULL, "frame descriptor is NULL");
+    if (f->width <= 0 || f->height <= 0) return fail(RMD_E_SHAPE, "frame %dx%d is not positive", f->width, f->height);
+    if ((long long)f->width * (long long)f->height > 0x7fffffffLL)
+        return fail(RMD_E_SHAPE, "frame %dx%d overflows int pixel indices", f->width, f->height);
+    if (f->buf_rows <= 0 || f->buf_row0 < 0 || f->buf_row0 + f->buf_rows > f->height)
+        return fail(RMD_E_ROWS, "buffer rows [%d,%d) outside frame height %d", f->buf_row0, f->buf_row0 + f->buf_rows, f->height);
+    return RMD_OK;
+}
+
+int check_rows_in_buffer(const rmd_svgf_frame_desc* f, int lo, int hi, const char* what)
+{
+    if (lo < 0) lo = 0;
+    if (hi > f->height) hi = f->height;
+    if (lo < f->buf_row0 || hi > f->buf_row0 + f->buf_rows)
+        return fail(RMD_E_ROWS, "%s needs rows [%d,%d) but the planes hold [%d,%d)", what, lo, hi,
+                    f->buf_row0, f->buf_row0 + f->buf_rows);
+    return RMD_OK;
+}
+
+struct Timer {
+    hipEvent_t start, stop;
+};
+
+}  // namespace rmd
+
+using namespace rmd;
+
+extern "C" {
+
+const char* rmd_last_error_string(void) { return g_err; }
+const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.1 (gfx950)"; }
+
+int rmd_malloc(void** ptr, size_t bytes)
+{
+    if (!ptr) return fail(RMD_E_NULL, "rmd_malloc: ptr is NULL");
+    *ptr = nullptr;
+    if (bytes == 0) return RMD_OK;
+    RMD_HIP(hipMalloc(ptr, bytes));
+    return RMD_OK;
+}
+
+int rmd_free(void* ptr)
+{
+    if (!ptr) return RMD_OK;
+    RMD_HIP(hipFree(ptr));
+    return RMD_OK;
+}
+
+int rmd_memset(void* ptr, int value, size_t bytes, void* stream)
+{
+    if (!ptr && bytes) return fail(RMD_E_NULL, "rmd_memset: ptr is NULL");
+    RMD_HIP(hipMemsetAsync(ptr, value, bytes, as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_memcpy_h2d(void* dst, const void* src, size_t bytes)
+{
+    if ((!dst || !src) && bytes) return fail(RMD_E_NULL, "rmd_memcpy_h2d: NULL pointer");
+    RMD_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return RMD_OK;
+}
+
+int rmd_memcpy_d2h(void* dst, const void* src, size_t bytes)
+{
+    if ((!dst || !src) && bytes) return fail(RMD_E_NULL, "rmd_memcpy_d2h: NULL pointer");
+    RMD_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return RMD_OK;
+}
+
+int rmd_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    if ((!dst || !src) && bytes) return fail(RMD_E_NULL, "rmd_memcpy_d2d: NULL pointer");
+    RMD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_memcpy_h2d_async(void* dst, const void* src, size_t bytes, void* stream)
+{
+    if ((!dst || !src) && bytes) return fail(RMD_E_NULL, "rmd_memcpy_h2d_async: NULL pointer");
+    RMD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream)
+{
+    if ((!dst || !src) && bytes) return fail(RMD_E_NULL, "rmd_memcpy_d2h_async: NULL pointer");
+    RMD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_host_alloc_pinned(void** ptr, size_t bytes)
+{
+    if (!ptr) return fail(RMD_E_NULL, "rmd_host_alloc_pinned: ptr is NULL");
+    RMD_HIP(hipHostMalloc(ptr, bytes, hipHostMallocDefault));
+    return RMD_OK;
+}
+
+int rmd_host_free_pinned(void* ptr)
+{
+    if (!ptr) return RMD_OK;
+    RMD_HIP(hipHostFree(ptr));
+    return RMD_OK;
+}
+
+int rmd_stream_create(void** stream)
+{
+    if (!stream) return fail(RMD_E_NULL, "rmd_stream_create: stream is NULL");
+    hipStream_t s;
+    RMD_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return RMD_OK;
+}
+
+int rmd_stream_destroy(void* stream)
+{
+    if (!stream) return RMD_OK;
+    RMD_HIP(hipStreamDestroy(as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_stream_sync(void* stream)
+{
+    RMD_HIP(hipStreamSynchronize(as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_device_sync(void)
+{
+    RMD_HIP(hipDeviceSynchronize());
+    return RMD_OK;
+}
+
+int rmd_device_count(int* count)
+{
+    if (!count) return fail(RMD_E_NULL, "rmd_device_count: count is NULL");
+    RMD_HIP(hipGetDeviceCount(count));
+    return RMD_OK;
+}
+
+int rmd_set_device(int device)
+{
+    RMD_HIP(hipSetDevice(device));
+    return RMD_OK;
+}
+
+int rmd_print_device_properties(void)
+{
+    int dev = 0;
+    RMD_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    RMD_HIP(hipGetDeviceProperties(&prop, dev));
+    // same facts the reference prints (name, shared memory, registers, warp size), restated for
+    // CDNA: wavefront width, CU count, LDS per workgroup / per CU, L2, memory clock x bus.
+    printf("Device name: %s (%s)\n", prop.name, prop.gcnArchName);
+    printf("Compute units: %d\n", prop.multiProcessorCount);
+    printf("Wavefront size: %d\n", prop.warpSize);
+    printf("LDS per workgroup: %.1f KB\n", prop.sharedMemPerBlock / 1024.0);
+    printf("LDS per compute unit: %.1f KB\n", prop.maxSharedMemoryPerMultiProcessor / 1024.0);
+    printf("Registers per workgroup: %d\n", prop.regsPerBlock);
+    printf("L2 cache: %.1f MB\n", prop.l2CacheSize / (1024.0 * 1024.0));
+    printf("Global memory: %.1f GB\n", prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    printf("Memory clock: %d kHz, bus width %d bits\n\n", prop.memoryClockRate, prop.memoryBusWidth);
+    return RMD_OK;
+}
+
+int rmd_timer_create(void** timer)
+{
+    if (!timer) return fail(RMD_E_NULL, "rmd_timer_create: timer is NULL");
+    Timer* t = new Timer();
+    hipError_t e = hipEventCreate(&t->start);
+    if (e == hipSuccess) e = hipEventCreate(&t->stop);
+    if (e != hipSuccess) { delete t; return hip_fail(e, "hipEventCreate"); }
+    *timer = t;
+    return RMD_OK;
+}
+
+int rmd_timer_destroy(void* timer)
+{
+    if (!timer) return RMD_OK;
+    Timer* t = static_cast<Timer*>(timer);
+    (void)hipEventDestroy(t->start);
+    (void)hipEventDestroy(t->stop);
+    delete t;
+    return RMD_OK;
+}
+
+int rmd_timer_start(void* timer, void* stream)
+{
+    if (!timer) return fail(RMD_E_NULL, "rmd_timer_start: timer is NULL");
+    RMD_HIP(hipEventRecord(static_cast<Timer*>(timer)->start, as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_timer_stop(void* timer, void* stream)
+{
+    if (!timer) return fail(RMD_E_NULL, "rmd_timer_stop: timer is NULL");
+    RMD_HIP(hipEventRecord(static_cast<Timer*>(timer)->stop, as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_timer_elapsed_ms(void* timer, float* ms)
+{
+    if (!timer || !ms) return fail(RMD_E_NULL, "rmd_timer_elapsed_ms: NULL argument");
+    Timer* t = static_cast<Timer*>(timer);
+    RMD_HIP(hipEventSynchronize(t->stop));
+    RMD_HIP(hipEventElapsedTime(ms, t->start, t->stop));
+    return RMD_OK;
+}
+
+}  // extern "C"

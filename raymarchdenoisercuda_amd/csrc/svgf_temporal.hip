@@ -1,0 +1,144 @@
+// svgf_temporal.hip — T pass: temporal reprojection + history accumulation (SURVEY Appendix A.T).
+//
+// Not in the reference (README.md:3-10 names "temporal accumulation"; no code exists).  One
+// thread per pixel; a wave owns 64 consecutive x so color / nd / motion are coalesced 16-byte
+// (8-byte for motion) loads.  The four bilinear history taps are gathers: neighbouring pixels
+// reproject to neighbouring history pixels, so each history line is fetched once from HBM and
+// re-served by L1/L2.  Algorithmic traffic 120 B/px: HBM-bound, no LDS needed.
+//
+// Bit-exact contract: q0, the 4-bit tap mask and the history length use only +,-,*,compare,
+// floor on fp32 in the oracle's operation order (this TU is built with -ffp-contract=off), so
+// they match oracle/svgf_oracle.c:orc_svgf_temporal bit for bit; so do the float outputs
+// (IEEE division, no transcendental functions in this pass).
+#include "common.h"
+
+namespace rmd {
+
+struct TemporalArgs {
+    Geom g;
+    const float4* color; const float4* nd; const float2* motion;
+    const float4* hist_color; const float4* hist_moments; const float4* prev_nd;
+    float4* t_color; float4* t_moments; int4* t_debug;
+    int row0, row1;
+    float alpha_color, alpha_moments, k_z, k_n;
+    int h_max, max_motion_rows;
+};
+
+__device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+
+__global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
+{
+    const Geom g = a.g;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = a.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= g.W || y >= a.row1) return;
+    const size_t i = pix_index(g, x, y);
+
+    const float4 c = a.color[i];
+    const float4 nd = a.nd[i];
+    const float2 m = a.motion[i];
+
+    // A.T.1
+    const float qx = (float)x + m.x, qy = (float)y + m.y;
+    const float fqx = floorf(qx), fqy = floorf(qy);
+    const int q0x = (int)fqx, q0y = (int)fqy;
+    const float fx = qx - fqx, fy = qy - fqy;
+    const float wk[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
+
+    // A.T.2: depth gradient by forward differences clamped at the border
+    const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
+    const float zr = a.nd[pix_index(g, x1, y)].w;
+    const float zd = a.nd[pix_index(g, x, y1)].w;
+    const float gz = fabsf(zr - nd.w) + fabsf(zd - nd.w);
+    const float zthr = a.k_z * (gz + 1e-2f);
+    const bool p_zero = is_zero3(nd);
+
+    int mask = 0;
+    float wsum = 0.0f, pcx = 0.0f, pcy = 0.0f, pcz = 0.0f, pm1 = 0.0f, pm2 = 0.0f;
+    float best_w = -1.0f;
+    int best_h = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!a.prev_nd) break;                     // no history yet (first frame / after a reset)
+        const int tx = q0x + (k & 1), ty = q0y + (k >> 1);
+        if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
+        if (abs(ty - y) > a.max_motion_rows) continue;
+        const size_t ti = pix_index(g, tx, ty);
+        const float4 pn = a.prev_nd[ti];
+        if (!(fabsf(pn.w - nd.w) <= zthr)) continue;
+        const bool ok_n = p_zero ? is_zero3(pn) : ((pn.x * nd.x + pn.y * nd.y + pn.z * nd.z) >= a.k_n);
+        if (!ok_n) continue;
+        mask |= 1 << k;
+        const float4 hc = a.hist_color[ti];
+        const float4 hm = a.hist_moments[ti];
+        const float w = wk[k];
+        wsum += w;
+        pcx += w * hc.x; pcy += w * hc.y; pcz += w * hc.z;
+        pm1 += w * hm.x; pm2 += w * hm.y;
+        if (w > best_w) { best_w = w; best_h = (int)hm.z; }
+    }
+
+    // A.T.3
+    int h;
+    if (mask != 0 && wsum >= 0.01f) {
+        pcx /= wsum; pcy /= wsum; pcz /= wsum; pm1 /= wsum; pm2 /= wsum;
+        h = min(best_h + 1, a.h_max);
+        h = max(h, 1);
+    } else {
+        h = 1;
+        pcx = pcy = pcz = 0.0f; pm1 = pm2 = 0.0f;
+    }
+
+    // A.T.4
+    const float inv_h = 1.0f / (float)h;
+    const float a_c = a.alpha_color > inv_h ? a.alpha_color : inv_h;
+    const float a_m = a.alpha_moments > inv_h ? a.alpha_moments : inv_h;
+    const float l = lum3(c.x, c.y, c.z);
+    const float m1 = lerpf(pm1, l, a_m), m2 = lerpf(pm2, l * l, a_m);
+    float var = m2 - m1 * m1;
+    if (!(var > 0.0f)) var = 0.0f;
+
+    a.t_color[i] = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
+    a.t_moments[i] = make_float4(m1, m2, (float)h, 0.0f);
+    if (a.t_debug) a.t_debug[i] = make_int4(q0x, q0y, mask, h);
+}
+
+}  // namespace rmd
+
+using namespace rmd;
+
+extern "C" int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+{
+    if (int e = check_frame_geometry(f)) return e;
+    if (!p) return fail(RMD_E_NULL, "rmd_svgf_temporal: params is NULL");
+    if (!f->color || !f->nd || !f->motion || !f->t_color || !f->t_moments)
+        return fail(RMD_E_NULL, "rmd_svgf_temporal: a required plane is NULL");
+    // hist_color / hist_moments / prev_nd all NULL = "no history": every pixel is a disocclusion
+    const bool has_hist = f->hist_color && f->hist_moments && f->prev_nd;
+    if (!has_hist && (f->hist_color || f->hist_moments || f->prev_nd))
+        return fail(RMD_E_NULL, "rmd_svgf_temporal: history planes must be all set or all NULL");
+    if (row0 < 0 || row1 > f->height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_svgf_temporal: rows [%d,%d) invalid", row0, row1);
+    if (p->max_motion_rows < 0 || p->h_max < 1) return fail(RMD_E_PARAM, "rmd_svgf_temporal: max_motion_rows/h_max invalid");
+    // current-frame planes: +1 row (depth gradient); history planes: +-(max_motion_rows) rows
+    if (int e = check_rows_in_buffer(f, row0, row1 + 1, "rmd_svgf_temporal (current frame)")) return e;
+    if (has_hist)
+        if (int e = check_rows_in_buffer(f, row0 - p->max_motion_rows, row1 + p->max_motion_rows, "rmd_svgf_temporal (history)")) return e;
+    const void* planes16[] = { f->color, f->nd, f->hist_color, f->hist_moments, f->prev_nd, f->t_color, f->t_moments, f->t_debug };
+    for (const void* q : planes16)
+        if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_temporal: float4 planes must be 16-byte aligned");
+    if (!aligned_to(f->motion, 8)) return fail(RMD_E_ALIGN, "rmd_svgf_temporal: motion must be 8-byte aligned");
+
+    TemporalArgs a;
+    a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
+    a.color = (const float4*)f->color; a.nd = (const float4*)f->nd; a.motion = (const float2*)f->motion;
+    a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float4*)f->hist_moments;
+    a.prev_nd = (const float4*)f->prev_nd;
+    a.t_color = (float4*)f->t_color; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
+    a.row0 = row0; a.row1 = row1;
+    a.alpha_color = p->alpha_color; a.alpha_moments = p->alpha_moments; a.k_z = p->k_z; a.k_n = p->k_n;
+    a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
+    dim3 grid((f->width + 63) / 64, (row1 - row0 + 3) / 4);
+    hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
+    RMD_LAUNCH_CHECK("svgf_temporal_kernel");
+    return RMD_OK;
+}

@@ -1,0 +1,126 @@
+// svgf_variance.hip — V pass: spatial variance estimate for pixels with a short history
+// (SURVEY Appendix A.V).  Not in the reference (README.md:3-10 names "variance-guided
+// filtering"; no code exists).
+//
+// One thread per pixel, a wave owns 64 consecutive x.  Pixels with h >= var_h_threshold copy
+// T's output (48 B read + 16 B written per pixel = the 64 B/px of SURVEY §8d).  Pixels on the
+// spatial path run a (2R+1)^2 edge-stopped window from global memory: those pixels are spatially
+// coherent (disocclusion bands, the first frames), so whole waves take one branch and the window
+// re-reads are served by L1/L2.  Frame statistics (sum of variance, spatial-path pixel count,
+// sum of history length, pixel count) are reduced across the wavefront with __shfl_xor
+// butterflies and committed with one atomic per wave.
+#include "common.h"
+
+namespace rmd {
+
+struct VarianceArgs {
+    Geom g;
+    const float4* t_color; const float4* t_moments; const float4* nd;
+    float4* v_color; float* stats;
+    int row0, row1;
+    int h_threshold, radius;
+    float sigma_n, sigma_z;
+};
+
+__global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
+{
+    const Geom g = a.g;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = a.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool active = x < g.W && y < a.row1;
+
+    float s_var = 0.0f, s_spatial = 0.0f, s_h = 0.0f, s_n = 0.0f;
+    if (active) {
+        const size_t i = pix_index(g, x, y);
+        const float4 c = a.t_color[i];
+        const int h = (int)a.t_moments[i].z;
+        float4 o = c;
+        if (h < a.h_threshold) {
+            const float4 nd = a.nd[i];
+            const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
+            const float gz = fabsf(a.nd[pix_index(g, x1, y)].w - nd.w) + fabsf(a.nd[pix_index(g, x, y1)].w - nd.w);
+            const float za = a.sigma_z * fmaxf(gz, 1e-8f);
+            const bool p_zero = is_zero3(nd);
+            float sw = 0.0f, scx = 0.0f, scy = 0.0f, scz = 0.0f, sl = 0.0f, sl2 = 0.0f;
+            const int R = a.radius;
+            for (int dx = -R; dx <= R; ++dx) {
+                const int tx = x + dx;
+                if (tx < 0 || tx >= g.W) continue;
+                for (int dy = -R; dy <= R; ++dy) {
+                    const int ty = y + dy;
+                    if (ty < 0 || ty >= g.H) continue;
+                    const size_t ti = pix_index(g, tx, ty);
+                    const float4 tc = a.t_color[ti];
+                    const float4 tn = a.nd[ti];
+                    // log2-domain edge-stopping weight: w = exp2(sigma_n*log2(max(0,n.n)) - w_z*log2 e)
+                    float e;
+                    const bool t_zero = is_zero3(tn);
+                    if (p_zero || t_zero) {
+                        e = (p_zero && t_zero) ? 0.0f : kNegInf;
+                    } else {
+                        const float d = __builtin_fmaf(nd.z, tn.z, __builtin_fmaf(nd.y, tn.y, nd.x * tn.x));
+                        e = a.sigma_n * fast_log2(fmaxf(d, 0.0f));
+                    }
+                    if (dx != 0 || dy != 0) {
+                        const float len = sqrtf((float)(dx * dx + dy * dy));
+                        e = __builtin_fmaf(-fabsf(nd.w - tn.w), kLog2e / (za * len + 1e-8f), e);
+                    }
+                    const float w = fast_exp2(e);
+                    const float tl = lum3(tc.x, tc.y, tc.z);
+                    sw += w;
+                    scx = __builtin_fmaf(w, tc.x, scx); scy = __builtin_fmaf(w, tc.y, scy); scz = __builtin_fmaf(w, tc.z, scz);
+                    sl = __builtin_fmaf(w, tl, sl); sl2 = __builtin_fmaf(w, tl * tl, sl2);
+                }
+            }
+            if (!(sw < 1e-10f)) {
+                const float el = sl / sw, el2 = sl2 / sw;
+                float var = el2 - el * el;
+                if (!(var > 0.0f)) var = 0.0f;
+                var *= 4.0f / (float)max(h, 1);
+                o = make_float4(scx / sw, scy / sw, scz / sw, var);
+            }
+            s_spatial = 1.0f;
+        }
+        a.v_color[i] = o;
+        s_var = o.w; s_h = (float)h; s_n = 1.0f;
+    }
+    if (a.stats) {
+        // wavefront reductions, one atomic per wave and statistic
+        s_var = wave_sum(s_var); s_spatial = wave_sum(s_spatial); s_h = wave_sum(s_h); s_n = wave_sum(s_n);
+        if ((threadIdx.x & 63) == 0 && s_n > 0.0f) {
+            atomicAdd(&a.stats[0], s_var); atomicAdd(&a.stats[1], s_spatial);
+            atomicAdd(&a.stats[2], s_h);   atomicAdd(&a.stats[3], s_n);
+        }
+    }
+}
+
+}  // namespace rmd
+
+using namespace rmd;
+
+extern "C" int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+{
+    if (int e = check_frame_geometry(f)) return e;
+    if (!p) return fail(RMD_E_NULL, "rmd_svgf_variance: params is NULL");
+    if (!f->t_color || !f->t_moments || !f->nd || !f->v_color) return fail(RMD_E_NULL, "rmd_svgf_variance: a required plane is NULL");
+    if (row0 < 0 || row1 > f->height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_svgf_variance: rows [%d,%d) invalid", row0, row1);
+    if (p->var_radius < 0 || p->var_radius > 16) return fail(RMD_E_PARAM, "rmd_svgf_variance: var_radius %d outside [0,16]", p->var_radius);
+    const int reach = p->var_radius > 1 ? p->var_radius : 1;
+    if (int e = check_rows_in_buffer(f, row0 - reach, row1 + reach, "rmd_svgf_variance")) return e;
+    const void* planes16[] = { f->t_color, f->t_moments, f->nd, f->v_color };
+    for (const void* q : planes16)
+        if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_variance: float4 planes must be 16-byte aligned");
+    if (f->t_color == f->v_color) return fail(RMD_E_BUFFER, "rmd_svgf_variance: t_color and v_color alias");
+
+    VarianceArgs a;
+    a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
+    a.t_color = (const float4*)f->t_color; a.t_moments = (const float4*)f->t_moments; a.nd = (const float4*)f->nd;
+    a.v_color = (float4*)f->v_color; a.stats = f->stats;
+    a.row0 = row0; a.row1 = row1;
+    a.h_threshold = p->var_h_threshold; a.radius = p->var_radius;
+    a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z;
+    dim3 grid((f->width + 63) / 64, (row1 - row0 + 3) / 4);
+    hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, as_stream(stream), a);
+    RMD_LAUNCH_CHECK("svgf_variance_kernel");
+    return RMD_OK;
+}

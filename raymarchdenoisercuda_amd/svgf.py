@@ -1,0 +1,171 @@
+"""Host-side SVGF interface over the C ABI (rmd_svgf_* in include/rmd_api.h).
+
+The reference only names SVGF (README.md:3-10); the pass semantics are SURVEY.md Appendix A.
+torch supplies device memory (float32 CUDA tensors) and nothing else; every pass runs in the
+HIP kernels of librmd.so.
+"""
+import ctypes as C
+
+import torch
+
+from ._lib import SvgfFrameDesc, SvgfParams, SynthDesc, check, lib
+from .filter import _stream_ptr
+
+PLANE_CHANNELS = {"color": 4, "nd": 4, "motion": 2, "hist_color": 4, "hist_moments": 4, "prev_nd": 4,
+                  "t_color": 4, "t_moments": 4, "t_debug": 4, "v_color": 4, "hist_color_out": 4,
+                  "out_color": 4}
+
+
+def default_params() -> SvgfParams:
+    p = SvgfParams()
+    lib.rmd_svgf_default_params(C.byref(p))
+    return p
+
+
+def frame_reach(params: SvgfParams):
+    """(input rows read, history rows read, hist_color rows produced, hist_moments rows produced)
+    above/below the output rows of a whole-frame call (include/rmd_api.h rmd_svgf_frame_reach)."""
+    r = (C.c_int * 4)()
+    check(lib.rmd_svgf_frame_reach(C.byref(params), C.byref(r)))
+    return tuple(int(v) for v in r)
+
+
+def _ptr(t, name, rows, width, channels, dtype=torch.float32):
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous CUDA {dtype} tensor")
+    if tuple(t.shape) != (rows, width, channels):
+        raise ValueError(f"{name}: shape {tuple(t.shape)} != {(rows, width, channels)}")
+    return t.data_ptr()
+
+
+def frame_desc(width, height, buf_row0=0, buf_rows=None, ping=(None, None), stats=None, **planes) -> SvgfFrameDesc:
+    """Descriptor over torch planes of shape [buf_rows, width, C] (caller keeps them alive)."""
+    buf_rows = height if buf_rows is None else buf_rows
+    d = SvgfFrameDesc()
+    d.width, d.height, d.buf_row0, d.buf_rows = width, height, buf_row0, buf_rows
+    for name, t in planes.items():
+        if name not in PLANE_CHANNELS:
+            raise KeyError(name)
+        dtype = torch.int32 if name == "t_debug" else torch.float32
+        setattr(d, name, _ptr(t, name, buf_rows, width, PLANE_CHANNELS[name], dtype))
+    d.ping[0] = _ptr(ping[0], "ping[0]", buf_rows, width, 4)
+    d.ping[1] = _ptr(ping[1], "ping[1]", buf_rows, width, 4)
+    if stats is not None:
+        if not (stats.is_cuda and stats.dtype == torch.float32 and stats.numel() >= 4):
+            raise ValueError("stats: expected a CUDA float32 tensor with >= 4 elements")
+        d.stats = stats.data_ptr()
+    return d
+
+
+def temporal(desc, params, row0, row1, stream=None):
+    check(lib.rmd_svgf_temporal(C.byref(desc), C.byref(params), row0, row1, _stream_ptr(stream)))
+
+
+def variance(desc, params, row0, row1, stream=None):
+    check(lib.rmd_svgf_variance(C.byref(desc), C.byref(params), row0, row1, _stream_ptr(stream)))
+
+
+def atrous(desc, params, iteration, src, dst, row0, row1, stream=None):
+    rows, width = desc.buf_rows, desc.width
+    check(lib.rmd_svgf_atrous(C.byref(desc), C.byref(params), iteration, _ptr(src, "in", rows, width, 4),
+                              _ptr(dst, "out", rows, width, 4), row0, row1, _stream_ptr(stream)))
+
+
+def frame(desc, params, row0, row1, stream=None):
+    check(lib.rmd_svgf_frame(C.byref(desc), C.byref(params), row0, row1, _stream_ptr(stream)))
+
+
+def synth_gbuffer(width, height, frame_index, buf_row0=0, buf_rows=None, seed=1234, pan=(1.25, -0.5),
+                  device="cuda", want_albedo=False, out=None, stream=None):
+    """Synthetic G-buffer of SURVEY §8(d) generated on the device: (color, nd, motion[, albedo])."""
+    buf_rows = height if buf_rows is None else buf_rows
+    if out is None:
+        color = torch.empty((buf_rows, width, 4), dtype=torch.float32, device=device)
+        nd = torch.empty_like(color)
+        motion = torch.empty((buf_rows, width, 2), dtype=torch.float32, device=device)
+    else:
+        color, nd, motion = out
+    albedo = torch.empty_like(color) if want_albedo else None
+    d = SynthDesc(width, height, buf_row0, buf_rows, seed, frame_index, pan[0], pan[1])
+    check(lib.rmd_synth_gbuffer(C.byref(d), color.data_ptr(), nd.data_ptr(), motion.data_ptr(),
+                                albedo.data_ptr() if want_albedo else None, _stream_ptr(stream)))
+    return (color, nd, motion, albedo) if want_albedo else (color, nd, motion)
+
+
+def convert_u8_to_f32(src_u8, renormalize_xyz=False, w_value=-1.0, stream=None):
+    """uint8 [H, W, 4] -> float32 [H, W, 4] (c/255, optional xyz renormalisation, w override)."""
+    out = torch.empty(src_u8.shape, dtype=torch.float32, device=src_u8.device)
+    check(lib.rmd_convert_u8_to_f32(src_u8.data_ptr(), out.data_ptr(), src_u8.shape[0] * src_u8.shape[1],
+                                    int(renormalize_xyz), float(w_value), _stream_ptr(stream)))
+    return out
+
+
+def convert_f32_to_u8(src_f32, albedo=None, stream=None):
+    out = torch.empty(src_f32.shape, dtype=torch.uint8, device=src_f32.device)
+    check(lib.rmd_convert_f32_to_u8(src_f32.data_ptr(), None if albedo is None else albedo.data_ptr(),
+                                    out.data_ptr(), src_f32.shape[0] * src_f32.shape[1], _stream_ptr(stream)))
+    return out
+
+
+class SvgfDenoiser:
+    """Cross-frame SVGF state for one device / one row strip.
+
+    Same plane routing as the C context (rmd_svgf_context_*), but the planes are torch tensors
+    so a row-strip deployment can hand their halo rows to torch.distributed (RCCL).  Planes hold
+    global rows [buf_row0, buf_row0+buf_rows); `denoise` produces rows [row0,row1).
+    """
+
+    def __init__(self, width, height, buf_row0=0, buf_rows=None, params=None, device="cuda", debug=False):
+        self.width, self.height = width, height
+        self.buf_row0 = buf_row0
+        self.buf_rows = height if buf_rows is None else buf_rows
+        self.params = params if params is not None else default_params()
+        self.device = device
+
+        def plane():
+            return torch.zeros((self.buf_rows, width, 4), dtype=torch.float32, device=device)
+
+        self.hist_color = [plane(), plane()]
+        self.hist_moments = [plane(), plane()]
+        self.t_color, self.v_color = plane(), plane()
+        self.ping = [plane(), plane()]
+        self.t_debug = torch.zeros((self.buf_rows, width, 4), dtype=torch.int32, device=device) if debug else None
+        self.stats = torch.zeros(4, dtype=torch.float32, device=device)
+        self.cur = 0
+        self.has_history = False
+        self.prev_nd = None
+
+    def reset_history(self):
+        self.has_history = False
+        self.prev_nd = None
+
+    def history(self):
+        """(hist_color, hist_moments) the NEXT denoise call reads."""
+        return self.hist_color[self.cur], self.hist_moments[self.cur]
+
+    def describe(self, color, nd, motion, out):
+        use_hist = self.has_history and self.prev_nd is not None
+        return frame_desc(
+            self.width, self.height, self.buf_row0, self.buf_rows,
+            color=color, nd=nd, motion=motion,
+            hist_color=self.hist_color[self.cur] if use_hist else None,
+            hist_moments=self.hist_moments[self.cur] if use_hist else None,
+            prev_nd=self.prev_nd if use_hist else None,
+            t_color=self.t_color, t_moments=self.hist_moments[self.cur ^ 1], t_debug=self.t_debug,
+            v_color=self.v_color, hist_color_out=self.hist_color[self.cur ^ 1],
+            ping=(self.ping[0], self.ping[1]), out_color=out, stats=self.stats)
+
+    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None):
+        """One frame.  `nd` is borrowed until the next call (it becomes prev_nd)."""
+        if out is None:
+            out = torch.empty_like(color)
+        row0 = max(self.buf_row0, 0) if row0 is None else row0
+        row1 = min(self.buf_row0 + self.buf_rows, self.height) if row1 is None else row1
+        d = self.describe(color, nd, motion, out)
+        frame(d, self.params, row0, row1, stream)
+        self.cur ^= 1
+        self.has_history = True
+        self.prev_nd = nd
+        return out

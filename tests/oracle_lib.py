@@ -1,0 +1,180 @@
+"""numpy/ctypes front end of oracle/liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package.  Builds the oracle with `make -C oracle` if the shared object is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+sys.path.insert(0, ROOT)
+from raymarchdenoisercuda_amd._lib import SvgfFrameDesc, SvgfParams, SynthDesc  # noqa: E402  (struct layouts only)
+
+
+def build_oracle():
+    """`make` is a no-op when liboracle.so is newer than its sources; without gcc/make (never the
+    case in this image) an existing .so is used as is."""
+    try:
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(ORACLE_SO):
+            raise
+    return ORACLE_SO
+
+
+def _load():
+    build_oracle()
+    lib = C.CDLL(ORACLE_SO)
+    P = C.c_void_p
+    lib.orc_box_level.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.orc_box_filter.argtypes = [P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.orc_box_filter_mt.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.orc_svgf_temporal.argtypes = [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int]
+    lib.orc_svgf_variance.argtypes = [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int]
+    lib.orc_svgf_atrous.argtypes = [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, P, P, C.c_int, C.c_int]
+    lib.orc_svgf_frame.argtypes = [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int]
+    lib.orc_svgf_pass_mt.argtypes = [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, P, P, C.c_int]
+    lib.orc_synth_gbuffer.argtypes = [C.POINTER(SynthDesc), P, P, P, P]
+    lib.orc_hash32.argtypes = [C.c_uint32] * 4
+    lib.orc_hash32.restype = C.c_uint32
+    lib.orc_convert_u8_to_f32.argtypes = [P, P, C.c_size_t, C.c_int, C.c_float]
+    lib.orc_convert_f32_to_u8.argtypes = [P, P, P, C.c_size_t]
+    lib.orc_hardware_threads.restype = C.c_int
+    for f in (lib.orc_box_level, lib.orc_box_filter, lib.orc_box_filter_mt, lib.orc_svgf_temporal, lib.orc_svgf_variance,
+              lib.orc_svgf_atrous, lib.orc_svgf_frame, lib.orc_svgf_pass_mt, lib.orc_synth_gbuffer,
+              lib.orc_convert_u8_to_f32, lib.orc_convert_f32_to_u8):
+        f.restype = None
+    return lib
+
+
+lib = _load()
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def default_params() -> SvgfParams:
+    """SURVEY Appendix A defaults (kept independent of librmd's rmd_svgf_default_params; a test compares them)."""
+    return SvgfParams(alpha_color=0.05, alpha_moments=0.2, h_max=32, k_z=10.0, k_n=0.9, max_motion_rows=64,
+                      var_h_threshold=4, var_radius=3, sigma_n=128.0, sigma_z=1.0, sigma_l=4.0,
+                      iterations=5, hist_iteration=0, atrous_variant=0, reserved0=0, reserved1=0)
+
+
+# ---- box filter ------------------------------------------------------------------------------
+def box_filter(render_rgba: np.ndarray, radius=2, depth=1, gray_from_r=False, threads=1) -> np.ndarray:
+    """render_rgba: uint8 [H, W, 4].  gray_from_r=True = filterKernelBaseline, False = filterKernelTiled."""
+    assert render_rgba.dtype == np.uint8 and render_rgba.ndim == 3 and render_rgba.shape[2] == 4
+    src = np.ascontiguousarray(render_rgba)
+    h, w, _ = src.shape
+    out = np.zeros_like(src)
+    if depth == 1 and threads > 1:
+        lib.orc_box_filter_mt(_p(src), _p(out), w, h, radius, int(gray_from_r), threads)
+        return out
+    b0 = np.zeros_like(src) if depth > 1 else None
+    b1 = np.zeros_like(src) if depth > 1 else None
+    lib.orc_box_filter(_p(src), _p(out), _p(b0), _p(b1), w, h, radius, depth, int(gray_from_r))
+    return out
+
+
+# ---- SVGF ------------------------------------------------------------------------------------
+class Frame:
+    """Host planes of one SVGF frame (numpy float32) + the descriptor the oracle reads."""
+
+    def __init__(self, width, height, color, nd, motion, hist_color=None, hist_moments=None, prev_nd=None, debug=True):
+        self.width, self.height = width, height
+        f4 = lambda: np.zeros((height, width, 4), np.float32)  # noqa: E731
+        self.color = np.ascontiguousarray(color, np.float32)
+        self.nd = np.ascontiguousarray(nd, np.float32)
+        self.motion = np.ascontiguousarray(motion, np.float32)
+        self.hist_color = None if hist_color is None else np.ascontiguousarray(hist_color, np.float32)
+        self.hist_moments = None if hist_moments is None else np.ascontiguousarray(hist_moments, np.float32)
+        self.prev_nd = None if prev_nd is None else np.ascontiguousarray(prev_nd, np.float32)
+        self.t_color, self.t_moments, self.v_color = f4(), f4(), f4()
+        self.t_debug = np.zeros((height, width, 4), np.int32) if debug else None
+        self.hist_color_out, self.out_color = f4(), f4()
+        self.ping = [f4(), f4()]
+        self.desc = SvgfFrameDesc()
+        d = self.desc
+        d.width, d.height, d.buf_row0, d.buf_rows = width, height, 0, height
+        for name in ("color", "nd", "motion", "hist_color", "hist_moments", "prev_nd", "t_color", "t_moments",
+                     "t_debug", "v_color", "hist_color_out", "out_color"):
+            arr = getattr(self, name)
+            setattr(d, name, None if arr is None else arr.ctypes.data)
+        d.ping[0], d.ping[1] = self.ping[0].ctypes.data, self.ping[1].ctypes.data
+
+
+def temporal(fr: Frame, p: SvgfParams, row0=0, row1=None):
+    lib.orc_svgf_temporal(C.byref(fr.desc), C.byref(p), row0, fr.height if row1 is None else row1)
+
+
+def variance(fr: Frame, p: SvgfParams, row0=0, row1=None):
+    lib.orc_svgf_variance(C.byref(fr.desc), C.byref(p), row0, fr.height if row1 is None else row1)
+
+
+def atrous(fr: Frame, p: SvgfParams, iteration, src: np.ndarray, dst: np.ndarray, row0=0, row1=None):
+    assert src.dtype == np.float32 and dst.dtype == np.float32 and src.flags.c_contiguous and dst.flags.c_contiguous
+    lib.orc_svgf_atrous(C.byref(fr.desc), C.byref(p), iteration, _p(src), _p(dst), row0, fr.height if row1 is None else row1)
+
+
+def frame(fr: Frame, p: SvgfParams, threads=1):
+    lib.orc_svgf_frame(C.byref(fr.desc), C.byref(p), threads)
+
+
+def pass_mt(fr: Frame, p: SvgfParams, which, iteration=0, src=None, dst=None, threads=1):
+    lib.orc_svgf_pass_mt(C.byref(fr.desc), C.byref(p), which, iteration, _p(src), _p(dst), threads)
+
+
+def synth_gbuffer(width, height, frame_index, buf_row0=0, buf_rows=None, seed=1234, pan=(1.25, -0.5), want_albedo=False):
+    buf_rows = height if buf_rows is None else buf_rows
+    color = np.zeros((buf_rows, width, 4), np.float32)
+    nd = np.zeros((buf_rows, width, 4), np.float32)
+    motion = np.zeros((buf_rows, width, 2), np.float32)
+    albedo = np.zeros((buf_rows, width, 4), np.float32) if want_albedo else None
+    d = SynthDesc(width, height, buf_row0, buf_rows, seed, frame_index, pan[0], pan[1])
+    lib.orc_synth_gbuffer(C.byref(d), _p(color), _p(nd), _p(motion), _p(albedo))
+    return (color, nd, motion, albedo) if want_albedo else (color, nd, motion)
+
+
+def convert_u8_to_f32(src_u8, renormalize_xyz=False, w_value=-1.0):
+    src = np.ascontiguousarray(src_u8)
+    out = np.zeros(src.shape, np.float32)
+    lib.orc_convert_u8_to_f32(_p(src), _p(out), src.shape[0] * src.shape[1], int(renormalize_xyz), w_value)
+    return out
+
+
+def convert_f32_to_u8(src_f32, albedo=None):
+    src = np.ascontiguousarray(src_f32, np.float32)
+    alb = None if albedo is None else np.ascontiguousarray(albedo, np.float32)
+    out = np.zeros(src.shape, np.uint8)
+    lib.orc_convert_f32_to_u8(_p(src), _p(alb), _p(out), src.shape[0] * src.shape[1])
+    return out
+
+
+def hardware_threads():
+    return int(lib.orc_hardware_threads())
+
+
+# ---- fixtures ---------------------------------------------------------------------------------
+def load_cornell(name="render"):
+    """tests/golden/cornell/<name>.png -> uint8 [500, 500, 4] RGBA with A=255 (what the reference's
+    Image(path, 4) yields, reference src/image.cpp:33-40)."""
+    from PIL import Image
+    im = np.array(Image.open(os.path.join(ROOT, "tests", "golden", "cornell", f"{name}.png")).convert("RGB"))
+    return np.concatenate([im, np.full(im.shape[:2] + (1,), 255, np.uint8)], axis=2).copy()
+
+
+def cornell_svgf_inputs():
+    """Cornell planes as SVGF inputs: color = render/255 (a=0), nd.xyz = renormalised
+    normal/255 (zero stays zero), nd.w = 1 (depth.png is saturated), motion = 0."""
+    color = convert_u8_to_f32(load_cornell("render"), False, 0.0)
+    nd = convert_u8_to_f32(load_cornell("normal"), True, 1.0)
+    motion = np.zeros(color.shape[:2] + (2,), np.float32)
+    return color, nd, motion
