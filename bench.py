@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — full SVGF (temporal + variance + 5 a-trous) throughput on synthetic G-buffers.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+A "step" is one frame: T + V + 5 x A over the whole frame (7 kernel launches), inputs resident in
+HBM before the timed region (all W+K frames of G-buffer are pre-generated on the device).
+  N = 1 : BASELINE.json configs[2], 3840x2160 synthetic G-buffer + radiance, fp32.
+  N > 1 : weak scaling, one 7680x1080 row strip (the pixel count of a 4K frame) per GPU, i.e. a
+          7680 x 1080N frame (N = 4 is exactly the 8K frame of configs[3]); ranks exchange the
+          history halo rows with rank+-1 over RCCL every frame (sharding.py).
+Rank 0 prints ONE JSON line.  `value` = Mpixels/s of the whole job.  `roofline` is measured live
+with HIP events around single launches of the dominant kernel (the a-trous iteration: 48 B/px
+algorithmic = 32 read + 16 written).  `cpu_baseline` times the scalar oracle
+(oracle/, a port: the reference has no CPU path) on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+ATROUS_BYTES_PER_PX = 48       # per iteration: color 16 + nd 16 read, color 16 written
+FULL_BYTES_PER_PX = 424        # T 120 + V 64 + 5 x 48
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-reps", type=int, default=30)
+    return ap.parse_args()
+
+
+def hip_event_ms(rmd, fn, reps):
+    """Average duration of fn() in ms, each call bracketed by HIP events on the launch stream (NULL)."""
+    timer = C.c_void_p()
+    rmd.check(rmd.lib.rmd_timer_create(C.byref(timer)))
+    times = []
+    ms = C.c_float()
+    for _ in range(reps):
+        rmd.check(rmd.lib.rmd_timer_start(timer, None))
+        fn()
+        rmd.check(rmd.lib.rmd_timer_stop(timer, None))
+        rmd.check(rmd.lib.rmd_timer_elapsed_ms(timer, C.byref(ms)))
+        times.append(ms.value)
+    rmd.lib.rmd_timer_destroy(timer)
+    return times
+
+
+def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps):
+    """Dominant kernel = the a-trous iteration.  Times each of the 5 iterations alone on the
+    frame's own planes (steady-state history), HIP events on the stream the kernel runs on."""
+    color, nd, motion = frames[-1]
+    desc = den.describe(color, nd, motion, den.ping[1])
+    p = den.params
+    row0, row1 = plan.row0, plan.row1
+    per_iter = []
+    src, dst = den.v_color, den.ping[0]
+    for it in range(p.iterations):
+        for _ in range(3):
+            rmd.svgf.atrous(desc, p, it, src, dst, row0, row1)
+        t = hip_event_ms(rmd, lambda: rmd.svgf.atrous(desc, p, it, src, dst, row0, row1), reps)
+        per_iter.append(statistics.mean(t))
+        src, dst = dst, (den.ping[1] if dst is den.ping[0] else den.ping[0])
+    px = width * rows_out
+    avg_ms = statistics.mean(per_iter)
+    achieved = ATROUS_BYTES_PER_PX * px / (avg_ms * 1e-3) / 1e9
+    # PMC-measured HBM bytes per launch, if a rocprofv3 --pmc pass of this command was reduced
+    # into profiles/ (tools/pmc_traffic.py); null otherwise.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("atrous_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {
+        "bound": "hbm", "kernel": "atrous_stream_kernel<S> (one a-trous iteration, avg over S=1,2,4,8,16)",
+        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": ATROUS_BYTES_PER_PX * px,
+        "avg_launch_ms": round(avg_ms, 5),
+        "per_iteration_ms": [round(v, 5) for v in per_iter],
+        "atrous_x5_ms": round(sum(per_iter), 5),
+        "atrous_x5_mpix_s": round(px / (sum(per_iter) * 1e-3) / 1e6, 1),
+    }
+
+
+def cpu_baseline():
+    """Scalar oracle, all host threads, on a bounded sample: 2 frames of full SVGF at 1920x1080
+    synthetic (the 2nd, with history, is timed).  A reported baseline, not a target."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as orc
+    w, h = 1920, 1080
+    cores = orc.hardware_threads()
+    p = orc.default_params()
+    hc = hm = pn = None
+    dt = None
+    for f in range(2):
+        c, nd, m = orc.synth_gbuffer(w, h, f)
+        fr = orc.Frame(w, h, c, nd, m, hc, hm, pn, debug=False)
+        t0 = time.perf_counter()
+        orc.frame(fr, p, threads=cores)
+        dt = time.perf_counter() - t0
+        hc, hm, pn = fr.hist_color_out, fr.t_moments, fr.nd
+    return {"value": round(w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "1 frame (2nd of 2) of full SVGF at 1920x1080 synthetic, scalar C oracle (gcc -O2, "
+                      "-ffp-contract=off), static row strips on all host threads", "seconds": round(dt, 3)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import raymarchdenoisercuda_amd as rmd        # ImportError if librmd.so is missing: there is no fallback
+    from raymarchdenoisercuda_amd import sharding
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    rmd.check(rmd.lib.rmd_set_device(local))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    if world == 1:
+        width, height = 3840, 2160
+        workload = "3840x2160 synthetic G-buffer + radiance, full SVGF fp32 (BASELINE configs[2])"
+    else:
+        width, height = 7680, 1080 * world
+        workload = (f"7680x{height} synthetic G-buffer, one 7680x1080 row strip per GPU (weak scaling; "
+                    "4 GPUs = the 8K frame of BASELINE configs[3]), full SVGF fp32, RCCL neighbour history halo")
+    p = rmd.default_params()
+    p.max_motion_rows = 8            # the synthetic pan moves <= 1.5 rows per frame
+    sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world)
+    plan = sd.plan
+    rows_out = plan.row1 - plan.row0
+
+    # all frames resident in HBM before timing (40 B/px/frame: sized for 288 GB, not streamed)
+    nframes = args.warmup + args.steps
+    frames = [sd.synth(f) for f in range(nframes)]
+    out = torch.empty_like(frames[0][0])
+    torch.cuda.synchronize()
+
+    def step(f):
+        c, nd, m = frames[f]
+        sd.denoise(c, nd, m, out)
+
+    for f in range(args.warmup):
+        step(f)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(args.warmup, nframes):
+        step(f)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    total_px = width * height * args.steps
+    value = total_px / dt / 1e6
+    result = {
+        "metric": "Mpixels/s full SVGF (temporal + variance + 5 a-trous), fp32",
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "frame": [width, height], "rows_per_gpu": rows_out,
+                   "parallelism": f"row-strip x{world}", "passes": "T + V + 5 x A (7 launches/frame)"},
+        "effective_GBps_full_svgf": round(FULL_BYTES_PER_PX * total_px / dt / 1e9, 1),
+    }
+    if world > 1:
+        result["halo_bytes_per_frame_rank0"] = sharding.halo_bytes(plan, width)
+
+    if rank == 0:
+        result["roofline"] = measure_roofline(rmd, torch, sd.den, frames, width, rows_out, plan, args.roofline_reps)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # free the device-side frame store first; the oracle needs host RAM only
+        result["cpu_baseline"] = cpu_baseline()
+    elif rank == 0:
+        result["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,36 @@
+// svgf.h — C++ face of the SVGF C ABI (rmd_svgf_* in rmd_api.h).  The reference only names SVGF
+// (README.md:3-10); pass semantics are SURVEY.md Appendix A.
+#ifndef RMD_SVGF_H
+#define RMD_SVGF_H
+
+#include "utils.h"
+
+using SvgfParams = rmd_svgf_params;
+using SvgfFrame = rmd_svgf_frame_desc;
+
+inline SvgfParams svgfDefaultParams() { SvgfParams p; rmd_svgf_default_params(&p); return p; }
+inline void svgfTemporal(const SvgfFrame& f, const SvgfParams& p, int row0, int row1, void* stream = nullptr) { rmdCheck(rmd_svgf_temporal(&f, &p, row0, row1, stream), "svgfTemporal"); }
+inline void svgfVariance(const SvgfFrame& f, const SvgfParams& p, int row0, int row1, void* stream = nullptr) { rmdCheck(rmd_svgf_variance(&f, &p, row0, row1, stream), "svgfVariance"); }
+inline void svgfAtrous(const SvgfFrame& f, const SvgfParams& p, int iteration, const float* in, float* out, int row0, int row1, void* stream = nullptr) { rmdCheck(rmd_svgf_atrous(&f, &p, iteration, in, out, row0, row1, stream), "svgfAtrous"); }
+inline void svgfFrame(const SvgfFrame& f, const SvgfParams& p, int row0, int row1, void* stream = nullptr) { rmdCheck(rmd_svgf_frame(&f, &p, row0, row1, stream), "svgfFrame"); }
+
+// Owner of the cross-frame history planes (move-only).
+class SvgfContext {
+    rmd_svgf_context* ctx = nullptr;
+public:
+    SvgfContext(int width, int height) { rmdCheck(rmd_svgf_context_create(width, height, 0, height, &ctx), "SvgfContext"); }
+    SvgfContext(int width, int height, int bufRow0, int bufRows) { rmdCheck(rmd_svgf_context_create(width, height, bufRow0, bufRows, &ctx), "SvgfContext"); }
+    SvgfContext(const SvgfContext&) = delete;
+    SvgfContext& operator=(const SvgfContext&) = delete;
+    SvgfContext(SvgfContext&& o) noexcept : ctx(o.ctx) { o.ctx = nullptr; }
+    ~SvgfContext() { rmd_svgf_context_destroy(ctx); }
+    void resetHistory(void* stream = nullptr) { rmdCheck(rmd_svgf_context_reset_history(ctx, stream), "resetHistory"); }
+    void denoise(const SvgfParams& p, const float* color, const float* nd, const float* motion, const float* prevNd,
+                 float* out, int row0, int row1, void* stream = nullptr)
+    {
+        rmdCheck(rmd_svgf_context_denoise(ctx, &p, color, nd, motion, prevNd, out, row0, row1, stream), "SvgfContext::denoise");
+    }
+    rmd_svgf_context* get() { return ctx; }
+};
+
+#endif

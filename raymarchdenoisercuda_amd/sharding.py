@@ -59,35 +59,47 @@ def _rows(plane, plan, lo, hi):
     return plane[lo - plan.buf_row0: hi - plan.buf_row0]
 
 
-def halo_ops(plan: StripPlan, hist_color, hist_moments, group=None):
-    """P2P ops that complete this rank's next-frame history halo.
-
-    From rank-1 it needs rows [row0-reach_hist, row0-have); from rank+1 rows [row1+have,
-    row1+reach_hist); symmetric sends.  Rows outside the frame do not exist and are skipped.
+def halo_plan(plan: StripPlan):
+    """The per-frame exchange of one rank as plain data: a list of
+    (kind, plane, lo, hi, peer) with kind in {"recv", "send"}, plane in {"color", "moments"} and
+    [lo,hi) GLOBAL rows.  From rank-1 a rank needs rows [row0-reach_hist, row0-have); from rank+1
+    rows [row1+have, row1+reach_hist); the sends mirror the neighbours' needs.  Rows outside the
+    frame do not exist and are skipped.  recv/send pairs of two neighbours appear in matching
+    order, so posting them as one batched group cannot deadlock.
     """
-    ops = []
+    steps = []
     if plan.world == 1:
-        return ops
+        return steps
     up, down = plan.rank - 1, plan.rank + 1
     H = plan.height
-    for plane, have in ((hist_color, plan.have_color), (hist_moments, plan.have_moments)):
+    for name, have in (("color", plan.have_color), ("moments", plan.have_moments)):
         if have >= plan.reach_hist:
             continue
         if up >= 0:
             lo, hi = max(0, plan.row0 - plan.reach_hist), max(0, plan.row0 - have)
             if hi > lo:
-                ops.append(dist.P2POp(dist.irecv, _rows(plane, plan, lo, hi), up, group))
+                steps.append(("recv", name, lo, hi, up))
             # rank-1's lower need [row0+have, row0+reach_hist) lies in this rank's strip
             lo, hi = min(H, plan.row0 + have), min(H, plan.row0 + plan.reach_hist)
             if hi > lo:
-                ops.append(dist.P2POp(dist.isend, _rows(plane, plan, lo, hi), up, group))
+                steps.append(("send", name, lo, hi, up))
         if down < plan.world:
             lo, hi = min(H, plan.row1 + have), min(H, plan.row1 + plan.reach_hist)
             if hi > lo:
-                ops.append(dist.P2POp(dist.irecv, _rows(plane, plan, lo, hi), down, group))
+                steps.append(("recv", name, lo, hi, down))
             lo, hi = max(0, plan.row1 - plan.reach_hist), max(0, plan.row1 - have)
             if hi > lo:
-                ops.append(dist.P2POp(dist.isend, _rows(plane, plan, lo, hi), down, group))
+                steps.append(("send", name, lo, hi, down))
+    return steps
+
+
+def halo_ops(plan: StripPlan, hist_color, hist_moments, group=None):
+    """torch.distributed P2P ops for halo_plan(plan) on this rank's history planes."""
+    planes = {"color": hist_color, "moments": hist_moments}
+    ops = []
+    for kind, name, lo, hi, peer in halo_plan(plan):
+        fn = dist.irecv if kind == "recv" else dist.isend
+        ops.append(dist.P2POp(fn, _rows(planes[name], plan, lo, hi), peer, group))
     return ops
 
 

@@ -84,6 +84,9 @@ def test_no_product_module_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(base, f), errors="replace").read()
                 # comments may cite the oracle, code may not use it
-                code = re.sub(r"#.*", "", text) if f.endswith(".py") else re.sub(r"//.*|/\*.*?\*/", "", text, flags=re.S)
+                if f.endswith(".py"):
+                    code = re.sub(r"#[^\n]*", "", text)
+                else:
+                    code = re.sub(r"//[^\n]*", "", re.sub(r"/\*.*?\*/", "", text, flags=re.S))
                 assert "liboracle" not in code and "oracle_lib" not in code and "oracle/" not in code, os.path.join(base, f)
                 assert not re.search(r"\borc_[a-z]", code), os.path.join(base, f)

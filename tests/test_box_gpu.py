@@ -1,0 +1,91 @@
+"""uchar4 filter parity on the GPU: HIP kernels (through the C ABI) vs the oracle and the
+SURVEY §8(c) known answers.  Bit-exact (RGB; .w is 0 here, uninitialised in the reference
+baseline, src/filter.cu:50)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_oracle_box import KNOWN  # noqa: E402
+
+
+def run_gpu(rmd, img, radius=2, depth=1, tiled=True, cache_input=True):
+    t = torch.from_numpy(img).cuda()
+    p = rmd.FilterParams(type=rmd.FilterParams.AVERAGE, depth=depth, radius=radius, cacheInput=cache_input)
+    out = rmd.box_filter(t, p, tiled=tiled)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("size", ["500", "256"])
+@pytest.mark.parametrize("kind,cache", [("baseline", True), ("tiled", False), ("tiled", True)])
+def test_cornell_known_answers(rmd, orc, cuda, size, kind, cache):
+    """BASELINE config 1 on its GPU twin.  cacheInput=true (LDS path) must equal the reference's
+    cacheInput=false result: the reference's own cached path has a stride bug."""
+    full = orc.load_cornell("render")
+    img = full if size == "500" else full[122:378, 122:378].copy()
+    out = run_gpu(rmd, img, 2, 1, tiled=(kind == "tiled"), cache_input=cache)
+    assert hashlib.sha256(np.ascontiguousarray(out[:, :, :3]).tobytes()).hexdigest() == KNOWN[(size, kind)]
+    assert (out[:, :, 3] == 0).all()
+
+
+@pytest.mark.parametrize("shape,r", [((1, 1), 2), ((3, 7), 0), ((5, 4), 3), ((37, 61), 2), ((16, 16), 9), ((130, 257), 5),
+                                     ((70, 66), 24), ((40, 40), 30)])
+@pytest.mark.parametrize("tiled,cache", [(False, True), (True, False), (True, True)])
+def test_edge_shapes(rmd, orc, cuda, shape, r, tiled, cache):
+    """Empty-ish and ragged inputs: 1x1, radius 0, radius larger than the image, sizes that are not
+    multiples of the 64x16 tile, the largest LDS radius (24) and one beyond it (direct fallback)."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
+    got = run_gpu(rmd, img, r, 1, tiled, cache)
+    want = orc.box_filter(img, r, 1, gray_from_r=not tiled)
+    assert (got == want).all()
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_multi_level_ping_pong(rmd, orc, cuda, tiled):
+    """depth>1 with the reference's plane routing (src/filter.cu:24-25), one launch per level."""
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (90, 150, 4), dtype=np.uint8)
+    for depth in (2, 3, 4):
+        assert (run_gpu(rmd, img, 2, depth, tiled) == orc.box_filter(img, 2, depth, gray_from_r=not tiled)).all()
+
+
+def test_1080p_full_size(rmd, orc, cuda):
+    """The reference's bench shape (src/test.cu:64-90): 1920x1080, radius 2, depth 1."""
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (1080, 1920, 4), dtype=np.uint8)
+    want = orc.box_filter(img, 2, 1, False, threads=8)
+    for cache in (False, True):
+        assert (run_gpu(rmd, img, 2, 1, True, cache) == want).all()
+    assert (run_gpu(rmd, img, 2, 1, False)[:, :, 0] == want[:, :, 0]).all()
+
+
+def test_4k_properties(rmd, cuda):
+    """Size-independent properties at 3840x2160: a constant image is a fixed point, the filter is
+    monotone, and LDS / direct paths agree."""
+    t = torch.full((2160, 3840, 4), 77, dtype=torch.uint8, device="cuda")
+    p = rmd.FilterParams(radius=2)
+    assert (rmd.box_filter(t, p)[:, :, :3] == 77).all()
+    rng = torch.Generator(device="cuda").manual_seed(3)
+    img = torch.randint(0, 256, (2160, 3840, 4), dtype=torch.uint8, device="cuda", generator=rng)
+    a = rmd.box_filter(img, rmd.FilterParams(radius=3, cacheInput=True))
+    b = rmd.box_filter(img, rmd.FilterParams(radius=3, cacheInput=False))
+    assert torch.equal(a, b)
+    brighter = torch.clamp(img.to(torch.int16) + 9, max=255).to(torch.uint8)
+    c = rmd.box_filter(brighter, rmd.FilterParams(radius=3))
+    assert (c[:, :, :3] >= a[:, :, :3]).all()
+
+
+def test_errors_surface_as_exceptions(rmd, cuda):
+    t = torch.zeros((8, 8, 4), dtype=torch.uint8, device="cuda")
+    g = rmd.make_gbuffer(t, torch.empty_like(t))
+    with pytest.raises(rmd.RmdError):
+        rmd.filterKernelTiled(g, rmd.FilterParams(depth=2))          # buffer[] missing
+    g2 = rmd.make_gbuffer(t, t.clone())
+    g2.denoised = g2.render
+    with pytest.raises(rmd.RmdError):
+        rmd.filterKernelBaseline(g2, rmd.FilterParams())              # aliasing

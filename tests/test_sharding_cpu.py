@@ -1,0 +1,106 @@
+"""Row-strip sharding logic on CPU: plan arithmetic and the torch.distributed halo exchange
+over gloo with world_size 2 and 3 (the N>1 path of bench.py; RCCL is used on GPUs)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raymarchdenoisercuda_amd import sharding
+
+REACH = (66, 73, 60, 65)          # frame_reach(default params with max_motion_rows=8)
+
+
+def test_strips_partition_the_frame():
+    for h, w in ((4320, 8), (2160, 4), (1000, 3), (420, 2)):
+        rows = [sharding.strip_rows(h, w, r) for r in range(w)]
+        assert rows[0][0] == 0 and rows[-1][1] == h
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in rows) - min(b - a for a, b in rows) <= 1
+
+
+def test_plan_buffers_cover_every_read():
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            p = sharding.make_plan(4320, world, rank, REACH)
+            assert p.buf_row0 == max(0, p.row0 - 73) and p.buf_row0 + p.buf_rows == min(4320, p.row1 + 73)
+            assert p.row1 - p.row0 == 4320 // world
+
+
+def test_short_strips_are_rejected():
+    with pytest.raises(ValueError):
+        sharding.make_plan(400, 8, 0, REACH)
+
+
+def test_sends_and_receives_pair_up():
+    """Every recv of a rank is matched by the same rows being sent by the owner, in order."""
+    world, height = 4, 2160
+    plans = [sharding.make_plan(height, world, r, REACH) for r in range(world)]
+    steps = [sharding.halo_plan(p) for p in plans]
+    for r in range(world):
+        for peer in (r - 1, r + 1):
+            if not 0 <= peer < world:
+                continue
+            recvs = [(n, lo, hi) for k, n, lo, hi, q in steps[r] if k == "recv" and q == peer]
+            sends = [(n, lo, hi) for k, n, lo, hi, q in steps[peer] if k == "send" and q == r]
+            assert recvs == sends and recvs
+            for _, lo, hi in recvs:
+                assert plans[peer].row0 <= lo and hi <= plans[peer].row1      # sent rows are owned rows
+    assert sharding.halo_plan(sharding.make_plan(height, 1, 0, REACH)) == []
+    assert sharding.halo_bytes(plans[1], 3840) == 2 * (13 + 8) * 3840 * 16
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _truth(rows, width, plane_id):
+    """What global row y of a plane must contain."""
+    y = torch.arange(rows[0], rows[1], dtype=torch.float32).view(-1, 1, 1)
+    x = torch.arange(width, dtype=torch.float32).view(1, -1, 1)
+    ch = torch.arange(4, dtype=torch.float32).view(1, 1, -1)
+    return y * 1000.0 + x + ch * 0.125 + plane_id * 0.5
+
+
+def _worker(rank, world, port, height, width, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        plan = sharding.make_plan(height, world, rank, REACH)
+        planes = []
+        for pid, have in ((0, plan.have_color), (1, plan.have_moments)):
+            t = torch.full((plan.buf_rows, width, 4), -1.0)
+            lo, hi = max(0, plan.row0 - have), min(height, plan.row1 + have)   # what the rank computed itself
+            t[lo - plan.buf_row0:hi - plan.buf_row0] = _truth((lo, hi), width, pid)
+            planes.append(t)
+        for _ in range(2):                                                   # twice: the exchange is per frame
+            n = sharding.exchange_history_halo(plan, planes[0], planes[1])
+        ok = n == len(sharding.halo_plan(plan))
+        lo, hi = max(0, plan.row0 - plan.reach_hist), min(height, plan.row1 + plan.reach_hist)
+        for pid, t in enumerate(planes):
+            ok = ok and torch.equal(t[lo - plan.buf_row0:hi - plan.buf_row0], _truth((lo, hi), width, pid))
+        result[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_exchange_over_gloo(world):
+    height, width = 600, 48
+    ctx = mp.get_context("spawn")
+    result = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, height, width, result)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [result.get(r) for r in range(world)] == [True] * world

@@ -1,0 +1,342 @@
+"""SVGF parity on the GPU: HIP kernels (through the C ABI) vs the CPU oracle and the committed
+golden vectors.  PARITY UNPINNED BY THE REFERENCE for these passes: the
+oracle restates SURVEY Appendix A.
+
+Tolerances: reprojection index q0, 4-bit tap mask, history length: bit-exact.
+T float planes: bit-exact (only +,-,*,/ in the oracle's order).  V and each A iteration:
+|gpu-ref| <= 1e-4*(1+|ref|); after 5 iterations <= 5e-4*(1+|ref|) on inputs in [0,16].
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL_PASS = 1e-4
+TOL_FRAME = 5e-4
+
+
+def close(got, ref, tol, what=""):
+    got = got.cpu().numpy() if isinstance(got, torch.Tensor) else got
+    err = np.abs(got.astype(np.float64) - ref.astype(np.float64)) / (1.0 + np.abs(ref.astype(np.float64)))
+    assert np.isfinite(got).all(), what
+    assert err.max() <= tol, f"{what}: max scaled error {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
+    return err.max()
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def gpu_frame_desc(rmd, fr, **over):
+    """Device copy of an oracle Frame's inputs + fresh output planes, and the descriptor."""
+    t = {k: dev(getattr(fr, k)) for k in ("color", "nd", "motion", "hist_color", "hist_moments", "prev_nd")}
+    for k in ("t_color", "t_moments", "v_color", "hist_color_out", "out_color"):
+        t[k] = torch.zeros((fr.height, fr.width, 4), dtype=torch.float32, device="cuda")
+    t["t_debug"] = torch.zeros((fr.height, fr.width, 4), dtype=torch.int32, device="cuda")
+    t.update(over)
+    ping = (torch.zeros_like(t["t_color"]), torch.zeros_like(t["t_color"]))
+    d = rmd.svgf.frame_desc(fr.width, fr.height, ping=ping, **t)
+    return d, t, ping
+
+
+def oracle_sequence(orc, width, height, frames, p, inputs=None):
+    """Runs the oracle over `frames` frames; returns the list of oracle Frames (with outputs)."""
+    out, hc, hm, pn = [], None, None, None
+    for f in range(frames):
+        c, nd, m = inputs[f] if inputs else orc.synth_gbuffer(width, height, f)
+        fr = orc.Frame(width, height, c, nd, m, hc, hm, pn)
+        orc.frame(fr, p, threads=8)
+        out.append(fr)
+        hc, hm, pn = fr.hist_color_out, fr.t_moments, fr.nd
+    return out
+
+
+SIZES = [(64, 48), (97, 53), (300, 70), (523, 301)]
+
+
+@pytest.mark.parametrize("width,height", SIZES)
+def test_temporal_bit_exact(rmd, orc, cuda, width, height):
+    p = orc.default_params()
+    for f, fr in enumerate(oracle_sequence(orc, width, height, 3, p)):
+        d, t, _ = gpu_frame_desc(rmd, fr)
+        rmd.svgf.temporal(d, p, 0, height)
+        torch.cuda.synchronize()
+        dbg = t["t_debug"].cpu().numpy()
+        assert (dbg == fr.t_debug).all(), f"frame {f}: q0/mask/h differ at {np.argwhere(dbg != fr.t_debug)[:4]}"
+        assert (t["t_color"].cpu().numpy() == fr.t_color).all(), f"frame {f}: t_color not bit-exact"
+        assert (t["t_moments"].cpu().numpy() == fr.t_moments).all(), f"frame {f}: t_moments not bit-exact"
+        if f > 0:
+            assert (dbg[..., 2] != 0).any() and (dbg[..., 3] > 1).any()      # history really used
+            assert (dbg[..., 3] == 1).any()                                  # and disocclusions exist
+
+
+def test_temporal_row_range_and_motion_limit(rmd, orc, cuda):
+    p = orc.default_params()
+    p.max_motion_rows = 1                         # pan (1.25,-0.5): taps at dy=-1,0 stay, moving regions may not
+    fr = oracle_sequence(orc, 97, 53, 2, p)[1]
+    d, t, _ = gpu_frame_desc(rmd, fr)
+    rmd.svgf.temporal(d, p, 10, 37)
+    torch.cuda.synchronize()
+    dbg = t["t_debug"].cpu().numpy()
+    assert (dbg[10:37] == fr.t_debug[10:37]).all()
+    assert (dbg[:10] == 0).all() and (dbg[37:] == 0).all()               # rows outside the range untouched
+
+
+@pytest.mark.parametrize("width,height", SIZES[:3])
+def test_variance_parity(rmd, orc, cuda, width, height):
+    p = orc.default_params()
+    for f, fr in enumerate(oracle_sequence(orc, width, height, 2, p)):
+        d, t, _ = gpu_frame_desc(rmd, fr, t_color=dev(fr.t_color), t_moments=dev(fr.t_moments))
+        stats = torch.zeros(4, device="cuda")
+        d.stats = stats.data_ptr()
+        rmd.svgf.variance(d, p, 0, height)
+        torch.cuda.synchronize()
+        close(t["v_color"], fr.v_color, TOL_PASS, f"v_color frame {f}")
+        h = fr.t_moments[..., 2]
+        spatial = h < p.var_h_threshold
+        # pass-through pixels are copied bit for bit
+        assert (t["v_color"].cpu().numpy()[~spatial] == fr.t_color[~spatial]).all()
+        s = stats.cpu().numpy()
+        assert s[3] == width * height and s[1] == spatial.sum() and s[2] == h.sum()
+        assert abs(s[0] - fr.v_color[..., 3].sum()) <= 1e-3 * (1 + fr.v_color[..., 3].sum())
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("width,height", SIZES)
+def test_atrous_each_iteration(rmd, orc, cuda, width, height, variant):
+    """Every iteration in isolation (oracle-fed input), both kernel variants."""
+    p = orc.default_params()
+    p.atrous_variant = variant
+    fr = oracle_sequence(orc, width, height, 2, p)[1]
+    d, t, ping = gpu_frame_desc(rmd, fr)
+    src = fr.v_color
+    for it in range(5):
+        ref = np.zeros_like(src)
+        orc.atrous(fr, p, it, src, ref)
+        out = torch.full((height, width, 4), float("nan"), device="cuda")
+        rmd.svgf.atrous(d, p, it, dev(src), out, 0, height)
+        torch.cuda.synchronize()
+        close(out, ref, TOL_PASS, f"a-trous iteration {it} variant {variant}")
+        src = ref
+
+
+@pytest.mark.parametrize("width,height", [(64, 48), (300, 70), (523, 301), (1920, 1080)])
+def test_stream_kernel_equals_direct_kernel_bitwise(rmd, cuda, width, height):
+    """The LDS row-streaming kernel and the direct kernel share their arithmetic: identical bits."""
+    c, nd, m = rmd.svgf.synth_gbuffer(width, height, 3)
+    c[..., 3] = torch.rand((height, width), device="cuda") * 0.3          # some variance to filter
+    d = rmd.svgf.frame_desc(width, height, nd=nd)
+    p = rmd.default_params()
+    src = c
+    for it in range(5):
+        outs = []
+        for variant in (1, 2):
+            p.atrous_variant = variant
+            o = torch.full_like(c, float("nan"))
+            rmd.svgf.atrous(d, p, it, src, o, 0, height)
+            outs.append(o)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1]), f"iteration {it}: {(outs[0] != outs[1]).sum().item()} values differ"
+        src = outs[1]
+
+
+def test_atrous_zero_normals_cornell(rmd, orc, cuda):
+    """Cornell normals are (0,0,0) on 65 % of the pixels: exercises the zero-normal
+    rules and the wave-level choice between the two tap paths."""
+    color, nd, motion = orc.cornell_svgf_inputs()
+    color[..., 3] = 0.02
+    h, w = color.shape[:2]
+    fr = orc.Frame(w, h, color, nd, motion)
+    p = orc.default_params()
+    d, t, _ = gpu_frame_desc(rmd, fr)
+    for variant in (1, 2):
+        p.atrous_variant = variant
+        src = color
+        for it in range(5):
+            ref = np.zeros_like(src)
+            orc.atrous(fr, p, it, src, ref)
+            out = torch.full((h, w, 4), float("nan"), device="cuda")
+            rmd.svgf.atrous(d, p, it, dev(src), out, 0, h)
+            torch.cuda.synchronize()
+            close(out, ref, TOL_PASS, f"cornell iteration {it} variant {variant}")
+            src = ref
+
+
+def test_atrous_row_ranges_match_full_frame(rmd, cuda):
+    """Any output row range gives the bits of the whole-frame run (basis of row-strip sharding)."""
+    width, height = 300, 200
+    c, nd, m = rmd.svgf.synth_gbuffer(width, height, 2)
+    c[..., 3] = 0.1
+    d = rmd.svgf.frame_desc(width, height, nd=nd)
+    p = rmd.default_params()
+    for it in range(5):
+        full = torch.zeros_like(c)
+        rmd.svgf.atrous(d, p, it, c, full, 0, height)
+        part = torch.full_like(c, -7.0)
+        rmd.svgf.atrous(d, p, it, c, part, 37, 151)
+        torch.cuda.synchronize()
+        assert torch.equal(part[37:151], full[37:151])
+        assert (part[:37] == -7.0).all() and (part[151:] == -7.0).all()
+
+
+def test_full_frame_sequence_vs_oracle_and_golden(rmd, orc, cuda):
+    """T + V + 5 x A through SvgfDenoiser for 3 frames, against the oracle and the committed goldens."""
+    width, height = 64, 48
+    p = orc.default_params()
+    ref = oracle_sequence(orc, width, height, 3, p)
+    golden = np.load(os.path.join(orc.ROOT, "tests", "golden", "svgf_golden.npz"))
+    den = rmd.SvgfDenoiser(width, height, params=p, debug=True)
+    for f, fr in enumerate(ref):
+        out = den.denoise(dev(fr.color), dev(fr.nd), dev(fr.motion))
+        torch.cuda.synchronize()
+        assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}: integer outputs"
+        assert (den.t_debug.cpu().numpy() == golden[f"synth_f{f}_t_debug"]).all()
+        close(out, fr.out_color, TOL_FRAME, f"frame {f} out_color")
+        close(out, golden[f"synth_f{f}_out_color"], TOL_FRAME, f"frame {f} out_color vs golden")
+        hc, hm = den.history()
+        close(hc, fr.hist_color_out, TOL_FRAME, f"frame {f} hist_color")
+        close(hm, fr.t_moments, TOL_FRAME, f"frame {f} hist_moments")
+
+
+def test_cornell_full_svgf(rmd, orc, cuda):
+    """BASELINE config 2 input (Cornell planes as float G-buffer), 2 static frames, full frame 500x500."""
+    color, nd, motion = orc.cornell_svgf_inputs()
+    h, w = color.shape[:2]
+    p = orc.default_params()
+    ref = oracle_sequence(orc, w, h, 2, p, inputs=[(color, nd, motion)] * 2)
+    den = rmd.SvgfDenoiser(w, h, params=p, debug=True)
+    for f, fr in enumerate(ref):
+        out = den.denoise(dev(color), dev(nd), dev(motion))
+        torch.cuda.synchronize()
+        assert (den.t_debug.cpu().numpy() == fr.t_debug).all()
+        close(out, fr.out_color, TOL_FRAME, f"cornell frame {f}")
+
+
+def test_c_context_matches_python_denoiser(rmd, cuda):
+    """rmd_svgf_context_* (the C-side owner of the history planes) gives the same frames."""
+    import ctypes as C
+    width, height = 200, 120
+    p = rmd.default_params()
+    ctx = C.c_void_p()
+    rmd.check(rmd.lib.rmd_svgf_context_create(width, height, 0, height, C.byref(ctx)))
+    den = rmd.SvgfDenoiser(width, height, params=p)
+    prev_nd = None
+    try:
+        for f in range(3):
+            c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
+            want = den.denoise(c, nd, m)
+            got = torch.empty_like(c)
+            rmd.check(rmd.lib.rmd_svgf_context_denoise(ctx, C.byref(p), c.data_ptr(), nd.data_ptr(), m.data_ptr(),
+                                                       None if prev_nd is None else prev_nd.data_ptr(), got.data_ptr(),
+                                                       0, height, None))
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"frame {f}"
+            prev_nd = nd
+    finally:
+        rmd.lib.rmd_svgf_context_destroy(ctx)
+
+
+def simulate_strips(rmd, width, height, world, frames, p):
+    """All ranks of a row-strip deployment in one process: each 'rank' owns a ShardedDenoiser,
+    the halo exchange is done by copying exactly the rows sharding.halo_plan() names."""
+    from raymarchdenoisercuda_amd import sharding
+    ranks = [sharding.ShardedDenoiser(width, height, params=p, rank=r, world=world) for r in range(world)]
+    for r in ranks:
+        r.world_for_exchange = world
+    outs = []
+    for f in range(frames):
+        full = torch.zeros((height, width, 4), device="cuda")
+        for r in ranks:
+            c, nd, m = r.synth(f)
+            o = r.den.denoise(c, nd, m, None, r.plan.row0, r.plan.row1)
+            full[r.plan.row0:r.plan.row1] = o[r.plan.row0 - r.plan.buf_row0:r.plan.row1 - r.plan.buf_row0]
+        for r in ranks:                                   # the exchange, by plan
+            hist = dict(zip(("color", "moments"), r.den.history()))
+            for kind, name, lo, hi, peer in sharding.halo_plan(r.plan):
+                if kind != "recv":
+                    continue
+                q = ranks[peer]
+                src = dict(zip(("color", "moments"), q.den.history()))[name]
+                assert q.plan.row0 <= lo and hi <= q.plan.row1, "a halo row must come from its owner"
+                hist[name][lo - r.plan.buf_row0:hi - r.plan.buf_row0] = src[lo - q.plan.buf_row0:hi - q.plan.buf_row0]
+        outs.append(full)
+    return outs
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_row_strips_are_bit_identical_to_one_gpu(rmd, cuda, world):
+    """SURVEY §8e 'Parity across G': strip outputs are the bits of the single-device result."""
+    width, height, frames = 160, 420, 4
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    single = rmd.SvgfDenoiser(width, height, params=p)
+    want = []
+    for f in range(frames):
+        c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
+        want.append(single.denoise(c, nd, m).clone())
+    got = simulate_strips(rmd, width, height, world, frames, p)
+    torch.cuda.synchronize()
+    for f in range(frames):
+        assert torch.equal(got[f], want[f]), f"world {world} frame {f}: {(got[f] != want[f]).sum().item()} values differ"
+
+
+def test_synth_generator_matches_oracle_bitwise(rmd, orc, cuda):
+    for (w, h, f) in [(64, 48, 0), (300, 70, 7), (523, 301, 59)]:
+        c, nd, m, al = rmd.svgf.synth_gbuffer(w, h, f, want_albedo=True)
+        rc, rnd, rm, ral = orc.synth_gbuffer(w, h, f, want_albedo=True)
+        torch.cuda.synchronize()
+        for got, ref, name in ((c, rc, "color"), (nd, rnd, "nd"), (m, rm, "motion"), (al, ral, "albedo")):
+            assert (got.cpu().numpy() == ref).all(), f"{name} {w}x{h} frame {f}"
+    cs, nds, ms = rmd.svgf.synth_gbuffer(300, 70, 7, buf_row0=13, buf_rows=31)
+    rc, rnd, rm = orc.synth_gbuffer(300, 70, 7)
+    assert (cs.cpu().numpy() == rc[13:44]).all() and (nds.cpu().numpy() == rnd[13:44]).all()
+
+
+def test_conversions_match_oracle(rmd, orc, cuda):
+    for name, renorm, w in (("render", False, 0.0), ("normal", True, 1.0), ("albedo", False, -1.0)):
+        img = orc.load_cornell(name)
+        got = rmd.svgf.convert_u8_to_f32(dev(img), renorm, w)
+        assert (got.cpu().numpy() == orc.convert_u8_to_f32(img, renorm, w)).all(), name
+    rng = np.random.default_rng(2)
+    f = (rng.random((50, 70, 4), dtype=np.float32) * 1.5 - 0.2)
+    al = rng.random((50, 70, 4), dtype=np.float32)
+    assert (rmd.svgf.convert_f32_to_u8(dev(f)).cpu().numpy() == orc.convert_f32_to_u8(f)).all()
+    assert (rmd.svgf.convert_f32_to_u8(dev(f), dev(al)).cpu().numpy() == orc.convert_f32_to_u8(f, al)).all()
+
+
+def test_4k_properties(rmd, cuda):
+    """BASELINE config 3 size (3840x2160), size-independent properties of the graded kernel:
+    constant images are fixed points of every iteration, the variance channel never grows, the
+    stream kernel equals the direct kernel on a sample of rows, outputs stay inside the input
+    range (convex combination)."""
+    width, height = 3840, 2160
+    p = rmd.default_params()
+    c = torch.empty((height, width, 4), device="cuda")
+    c[..., 0], c[..., 1], c[..., 2], c[..., 3] = 0.25, 0.5, 0.75, 0.1
+    nd = torch.zeros_like(c); nd[..., 2] = 1.0; nd[..., 3] = 7.0
+    d = rmd.svgf.frame_desc(width, height, nd=nd)
+    for it in range(5):
+        o = torch.empty_like(c)
+        rmd.svgf.atrous(d, p, it, c, o, 0, height)
+        assert torch.allclose(o[..., :3], c[..., :3], rtol=2e-6, atol=0)
+        assert (o[..., 3] <= 0.1 * (1 + 1e-6)).all() and (o[..., 3] > 0).all()
+    c, nd, m = rmd.svgf.synth_gbuffer(width, height, 5)
+    c[..., 3] = 0.05
+    d = rmd.svgf.frame_desc(width, height, nd=nd)
+    lo, hi = c[..., :3].min().item(), c[..., :3].max().item()
+    src = c
+    for it in range(5):
+        p.atrous_variant = 2
+        o = torch.empty_like(c)
+        rmd.svgf.atrous(d, p, it, src, o, 0, height)
+        assert o[..., :3].min().item() >= lo - 1e-4 and o[..., :3].max().item() <= hi + 1e-4
+        p.atrous_variant = 1
+        for (r0, r1) in ((0, 40), (1061, 1101), (2120, 2160)):
+            chk = torch.empty_like(c)
+            rmd.svgf.atrous(d, p, it, src, chk, r0, r1)
+            assert torch.equal(chk[r0:r1], o[r0:r1]), f"iteration {it} rows {r0}:{r1}"
+        src = o
+    torch.cuda.synchronize()
