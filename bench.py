@@ -146,6 +146,7 @@ def main():
                     "4 GPUs = the 8K frame of BASELINE configs[3]), full SVGF fp32, RCCL neighbour history halo")
     p = rmd.default_params()
     p.max_motion_rows = 8            # the synthetic pan moves <= 1.5 rows per frame
+    p.atrous_variant = int(os.environ.get("RMD_ATROUS_VARIANT", "0"))   # 0 = library default (experiments only)
     sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world)
     plan = sd.plan
     rows_out = plan.row1 - plan.row0

@@ -6,6 +6,11 @@ The library is the product: there is NO CPU fallback.  Importing this module wit
 import ctypes as C
 import os
 
+# torch ships its own HIP runtime (libamdhip64.so under torch/lib).  It has to be in the process
+# before librmd.so is dlopen()ed, otherwise librmd pulls in /opt/rocm's copy first and the two
+# runtimes disagree about the devices ("no ROCm-capable device is detected" on the first launch).
+import torch  # noqa: F401  (device allocator for the host mirror; imported here for load order)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librmd.so")
 

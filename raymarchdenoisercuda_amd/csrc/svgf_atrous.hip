@@ -13,26 +13,32 @@
 //            (rows y = r mod S): a tap at +-S, +-2S rows stays in the pixel's lattice.  A
 //            workgroup (4 wave64 = 256 threads) owns a 256-pixel-wide column strip of one
 //            lattice inside one band of rows and walks down it; a ring of 6 lattice rows
-//            (color + nd, width 256 + 4S) lives in LDS, so every input row is fetched from
-//            L2/HBM once per strip as 16-byte-per-lane coalesced segments and each of the 25
-//            taps is a conflict-free ds_read_b128 with an immediate offset.  Each thread
-//            produces two vertically adjacent lattice pixels per step (30 tap fetches for 50
-//            weight evaluations), the next two lattice rows are prefetched into registers while
-//            the current pair is computed.  Workgroup ids are remapped so that each XCD owns a
-//            contiguous run of (band, strip, lattice) work: neighbouring strips / lattices, which
-//            share halo columns and the +-1 variance rows, hit the same 4 MiB L2.
-//            Algorithmic traffic 48 B/px/iteration (32 read + 16 written), SURVEY §8d.
+//            (width 256 + 4S) lives in LDS, so every input row is fetched from L2/HBM once per
+//            strip as 16-byte-per-lane coalesced segments and each of the 25 taps is a
+//            conflict-free ds_read_b128 with an immediate offset.  Each thread produces two
+//            vertically adjacent lattice pixels (A, B) per step: 30 tap fetches serve 50 weight
+//            evaluations, and the 40 evaluations whose tap both pixels share run as PACKED f32
+//            (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on the (A,B) register pair with the tap
+//            value broadcast through op_sel).  The next two lattice rows are prefetched into
+//            registers while the current pair is computed.  Workgroup ids are remapped so that
+//            each XCD owns a contiguous run of (band, strip, lattice) work: neighbouring strips /
+//            lattices, which share halo columns and the +-1 variance rows, hit the same L2.
 //
-// The weights are evaluated in the log2 domain (one v_log_f32 + one v_exp_f32 per tap):
-//   w = exp2( log2 k + sigma_n*log2(max(0,n_p.n_t)) - |dz|*log2e/(za*len+1e-8) - |dl|*log2e/l_den )
+// Measured on MI355X this pass is VALU-issue bound, not HBM bound (tools/microbench/valu_rate:
+// one SIMD retires a wave64 f32 op every ~3.7-5 cycles, a transcendental every ~8.5, and a
+// packed op every ~5.5-7): 25 taps x (3 FMA dot + log2 + exp2 + 2 edge terms + 5 accumulates)
+// per pixel costs more issue slots than 48 B/px cost HBM time.  Hence the instruction diet:
+//   - weights in the log2 domain, ONE v_log_f32 + ONE v_exp_f32 per tap:
+//       w = exp2( log2 k + sigma_n*log2(clamp01(n_p.n_t)) - |dz|*log2e/(za*len+1e-8) - |dl|*log2e/l_den )
+//   - luminance is computed once per STAGED pixel, not per tap: LDS holds (lum, r, g, var);
+//     blue is accumulated through lum and recovered at the end, b = (L - .2126R - .7152G)/.0722
+//   - normals are unit length by contract, so max(0, n.n) is applied as a [0,1] clamp.
 #include "common.h"
 #include <type_traits>
 
-#ifndef RMD_ATROUS_COLBUF
-#define RMD_ATROUS_COLBUF 1   // tap columns in flight: 2 = fetch next while weighting current (spills at 256 VGPRs)
-#endif
-
 namespace rmd {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct AtrousArgs {
     Geom g;
@@ -46,69 +52,162 @@ struct AtrousArgs {
 
 // log2 of the B3-spline taps {3/8, 1/4, 1/16} (reference src/filter.cu:10)
 __device__ constexpr float kLogB3[3] = { -1.41503749927884381855f, -2.0f, -4.0f };
-// 3x3 Gaussian variance prefilter: centre, edge, corner
-__device__ constexpr float kG3[3] = { 0.25f, 0.125f, 0.0625f };
+constexpr float kLumR = 0.2126f, kLumG = 0.7152f, kLumB = 0.0722f;
 
+// ---- lane-generic helpers: the SAME operations on one pixel (float) or on the (A,B) pair (f2) --
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f2    fma_(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+__device__ __forceinline__ f2    clamp01(f2 x) { return f2{ clamp01(x.x), clamp01(x.y) }; }
+__device__ __forceinline__ float log2_(float x) { return fast_log2(x); }
+__device__ __forceinline__ f2    log2_(f2 x) { return f2{ fast_log2(x.x), fast_log2(x.y) }; }
+__device__ __forceinline__ float exp2_(float x) { return fast_exp2(x); }
+__device__ __forceinline__ f2    exp2_(f2 x) { return f2{ fast_exp2(x.x), fast_exp2(x.y) }; }
+__device__ __forceinline__ float bc(float v, float) { return v; }          // broadcast a tap scalar
+__device__ __forceinline__ f2    bc(float v, f2) { return f2{ v, v }; }
+
+// A staged tap: color plane holds (lum, r, g, var), nd plane (nx, ny, nz, z).
+struct Tap { float4 c, n; };
+
+__device__ __forceinline__ float4 to_lrgv(const float4 rgbv)
+{
+    return make_float4(lum3(rgbv.x, rgbv.y, rgbv.z), rgbv.x, rgbv.y, rgbv.w);
+}
+
+// Per-pixel constants.  T = float for one pixel, f2 for the (A,B) pair.
+template <class T>
 struct Center {
-    float nx, ny, nz, z, lum, il;
-    float iz[5];      // log2e/(za*len+1e-8) for len = 1, sqrt2, 2, sqrt5, 2*sqrt2
-    bool zero;        // centre normal is (0,0,0)
+    T nx, ny, nz, z, lum, il;
 };
-struct Acc { float sw, sr, sg, sb, sv; };
+struct CenterAux {          // per pixel, not packed (edge terms use abs/neg source modifiers)
+    float iz[5];            // log2e/(za*len+1e-8) for len = 1, sqrt2, 2, sqrt5, 2*sqrt2
+    bool zero;              // centre normal is (0,0,0)
+};
+template <class T>
+struct Acc { T sw, sl, sr, sg, sv; };
 
 __device__ __forceinline__ int len_class(int adx, int ady)
 {
-    // (adx,ady) in {0,1,2}^2 minus (0,0) -> index into Center::iz
     const int m = adx * adx + ady * ady;            // 1,2,4,5,8
     return m == 1 ? 0 : m == 2 ? 1 : m == 4 ? 2 : m == 5 ? 3 : 4;
 }
 
-__device__ __forceinline__ Center make_center(const float4 c, const float4 n, float var_c, float gz,
-                                              float sigma_z, float sigma_l, float step)
+// A.A.1: 3x3 Gaussian {1/4, 1/8, 1/16} of the variance, interior form (weights sum to 1).
+__device__ __forceinline__ float prefilter9(float ul, float l, float dl, float u, float c, float d, float ur, float r, float dr)
 {
-    Center k;
-    k.nx = n.x; k.ny = n.y; k.nz = n.z; k.z = n.w;
-    k.zero = is_zero3(n);
-    k.lum = lum3(c.x, c.y, c.z);
+    float v = 0.0625f * ul;
+    v = fma_(0.125f, l, v);  v = fma_(0.0625f, dl, v);
+    v = fma_(0.125f, u, v);  v = fma_(0.25f, c, v);   v = fma_(0.125f, d, v);
+    v = fma_(0.0625f, ur, v); v = fma_(0.125f, r, v); v = fma_(0.0625f, dr, v);
+    return v;
+}
+
+__device__ __forceinline__ void make_center(const Tap& t, float var_c, float gz, float sigma_z, float sigma_l, float step,
+                                            Center<float>& k, CenterAux& x)
+{
+    k.nx = t.n.x; k.ny = t.n.y; k.nz = t.n.z; k.z = t.n.w;
+    k.lum = t.c.x;
+    x.zero = is_zero3(t.n);
     const float vc = var_c > 0.0f ? var_c : 0.0f;
-    k.il = kLog2e * fast_rcp(sigma_l * sqrtf(vc) + 1e-8f);
+    k.il = kLog2e * fast_rcp(fma_(sigma_l, __builtin_amdgcn_sqrtf(vc), 1e-8f));
     const float za = sigma_z * fmaxf(gz, 1e-8f) * step;
-    k.iz[0] = kLog2e * fast_rcp(za * 1.0f + 1e-8f);
-    k.iz[1] = kLog2e * fast_rcp(za * 1.41421356237309504880f + 1e-8f);
-    k.iz[2] = kLog2e * fast_rcp(za * 2.0f + 1e-8f);
-    k.iz[3] = kLog2e * fast_rcp(za * 2.23606797749978969641f + 1e-8f);
-    k.iz[4] = kLog2e * fast_rcp(za * 2.82842712474619009760f + 1e-8f);
+    x.iz[0] = kLog2e * fast_rcp(za + 1e-8f);
+    x.iz[1] = kLog2e * fast_rcp(fma_(za, 1.41421356237309504880f, 1e-8f));
+    x.iz[2] = kLog2e * fast_rcp(fma_(za, 2.0f, 1e-8f));
+    x.iz[3] = kLog2e * fast_rcp(fma_(za, 2.23606797749978969641f, 1e-8f));
+    x.iz[4] = kLog2e * fast_rcp(fma_(za, 2.82842712474619009760f, 1e-8f));
+}
+
+__device__ __forceinline__ f2 pair_of(float a, float b)
+{
+    // opaque to the optimizer: without this the (A,B) pairs are assembled by spilling both
+    // Center<float> structs to scratch and reloading overlapping <2 x float>s
+    asm("" : "+v"(a), "+v"(b));
+    return f2{ a, b };
+}
+__device__ __forceinline__ Center<f2> pack(const Center<float> a, const Center<float> b)
+{
+    Center<f2> k;
+    k.nx = pair_of(a.nx, b.nx); k.ny = pair_of(a.ny, b.ny); k.nz = pair_of(a.nz, b.nz); k.z = pair_of(a.z, b.z);
+    k.lum = pair_of(a.lum, b.lum); k.il = pair_of(a.il, b.il);
     return k;
 }
 
-// One tap.  e0 = log2 k (or -inf for a tap outside the frame: w becomes exactly 0).
-// ZERO_AWARE=false assumes the centre normal is non-zero (a zero tap normal then gives
-// log2(0) = -inf -> w = 0, as Appendix A.A.2 requires); true also handles zero centres.
-template <bool ZERO_AWARE>
-__device__ __forceinline__ void tap_accum(Acc& s, const Center& k, const float4 tc, const float4 tn, float tl,
-                                          float e0, int adx, int ady, float sigma_n)
+// The part of a tap weight that is the same code for one pixel and for the pair:
+// returns e = e0 + sigma_n*log2(clamp01(n_p.n_t)), and the signed depth / luminance differences.
+template <class T>
+__device__ __forceinline__ T tap_normal_term(const Center<T>& k, const Tap& t, T e0, float sigma_n, T& dz, T& dl)
 {
-    const float d = __builtin_fmaf(k.nz, tn.z, __builtin_fmaf(k.ny, tn.y, k.nx * tn.x));
-    float e = __builtin_fmaf(sigma_n, fast_log2(fmaxf(d, 0.0f)), e0);
-    if (ZERO_AWARE) {
-        const bool tz = is_zero3(tn);
-        if (k.zero) e = tz ? e0 : kNegInf;
-    }
-    if (adx | ady) e = __builtin_fmaf(-fabsf(k.z - tn.w), k.iz[len_class(adx, ady)], e);
-    e = __builtin_fmaf(-fabsf(k.lum - tl), k.il, e);
-    const float w = fast_exp2(e);
-    s.sw += w;
-    s.sr = __builtin_fmaf(w, tc.x, s.sr);
-    s.sg = __builtin_fmaf(w, tc.y, s.sg);
-    s.sb = __builtin_fmaf(w, tc.z, s.sb);
-    s.sv = __builtin_fmaf(w * w, tc.w, s.sv);
+    T d = k.nx * bc(t.n.x, T{});
+    d = fma_(k.ny, bc(t.n.y, T{}), d);
+    d = clamp01(fma_(k.nz, bc(t.n.z, T{}), d));
+    dz = k.z - bc(t.n.w, T{});
+    dl = k.lum - bc(t.c.x, T{});
+    return fma_(bc(sigma_n, T{}), log2_(d), e0);
 }
 
-__device__ __forceinline__ float4 finish(const Acc& s, const float4 c)
+// One lane's edge terms (abs / neg are free source modifiers of v_fma_f32).
+template <bool ZERO_AWARE>
+__device__ __forceinline__ float tap_edge_terms(float e, float e0, float dz, float dl, float il, const CenterAux& x,
+                                                bool tap_zero, int adx, int ady)
 {
-    if (s.sw < 1e-10f) return c;                       // A.A.3 pass-through
-    const float inv = fast_rcp(s.sw);
-    return make_float4(s.sr * inv, s.sg * inv, s.sb * inv, s.sv * inv * inv);
+    if (ZERO_AWARE) {   // Appendix A.A.2: both normals zero => w_n = 1, exactly one zero => 0
+        if (x.zero) e = tap_zero ? e0 : kNegInf;
+    }
+    if (adx | ady) e = fma_(-fabsf(dz), x.iz[len_class(adx, ady)], e);
+    return fma_(-fabsf(dl), il, e);
+}
+
+template <class T>
+__device__ __forceinline__ void tap_accumulate(Acc<T>& s, T w, const Tap& t)
+{
+    s.sw += w;
+    s.sl = fma_(w, bc(t.c.x, T{}), s.sl);
+    s.sr = fma_(w, bc(t.c.y, T{}), s.sr);
+    s.sg = fma_(w, bc(t.c.z, T{}), s.sg);
+    s.sv = fma_(w * w, bc(t.c.w, T{}), s.sv);
+}
+
+// one pixel, one tap
+template <bool ZERO_AWARE>
+__device__ __forceinline__ void tap_single(Acc<float>& s, const Center<float>& k, const CenterAux& x, const Tap& t,
+                                           float e0, int adx, int ady, float sigma_n)
+{
+    float dz, dl;
+    float e = tap_normal_term<float>(k, t, e0, sigma_n, dz, dl);
+    e = tap_edge_terms<ZERO_AWARE>(e, e0, dz, dl, k.il, x, ZERO_AWARE && is_zero3(t.n), adx, ady);
+    tap_accumulate<float>(s, exp2_(e), t);
+}
+
+// the (A,B) pair sharing one tap: dyA / dyB are the tap's row offsets seen from A and from B
+template <bool ZERO_AWARE>
+__device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const CenterAux& xa, const CenterAux& xb,
+                                         const Tap& t, f2 e0, int adx, int adyA, int adyB, float sigma_n)
+{
+    f2 dz, dl;
+    const f2 e = tap_normal_term<f2>(k, t, e0, sigma_n, dz, dl);
+    const bool tz = ZERO_AWARE && is_zero3(t.n);
+    // The edge terms stay scalar (|.| and - are free source modifiers of v_fma_f32, packed f32 has
+    // no abs).  The empty asm keeps the optimizer from re-vectorising them: it would gather the
+    // per-pixel iz[] constants into <2 x float> through a scratch array.
+    float ex = e.x, ey = e.y;
+    asm("" : "+v"(ex), "+v"(ey));
+    ex = tap_edge_terms<ZERO_AWARE>(ex, e0.x, dz.x, dl.x, k.il.x, xa, tz, adx, adyA);
+    ey = tap_edge_terms<ZERO_AWARE>(ey, e0.y, dz.y, dl.y, k.il.y, xb, tz, adx, adyB);
+    tap_accumulate<f2>(s, f2{ exp2_(ex), exp2_(ey) }, t);
+}
+
+// A.A.3.  c = the centre in (lum, r, g, var) form.
+__device__ __forceinline__ float4 finish(float sw, float sl, float sr, float sg, float sv, const float4 c)
+{
+    float L, R, G, V;
+    if (sw < 1e-10f) { L = c.x; R = c.y; G = c.z; V = c.w; }      // pass-through
+    else {
+        const float inv = fast_rcp(sw);
+        L = sl * inv; R = sr * inv; G = sg * inv; V = sv * inv * inv;
+    }
+    const float B = fma_(-kLumG, G, fma_(-kLumR, R, L)) * (1.0f / kLumB);
+    return make_float4(R, G, B, V);
 }
 
 // ---------------------------------------------------------------------------------- direct
@@ -120,27 +219,40 @@ __global__ __launch_bounds__(256) void atrous_direct_kernel(AtrousArgs a)
     if (x >= g.W || y >= a.row1) return;
     const int s = a.step;
     const size_t i = pix_index(g, x, y);
-    const float4 c = a.in[i];
-    const float4 n = a.nd[i];
+    Tap ctr;
+    ctr.c = to_lrgv(a.in[i]);
+    ctr.n = a.nd[i];
 
     // A.A.1: 3x3 Gaussian prefilter of the variance, OOB skipped + renormalised
-    float gsum = 0.0f, vsum = 0.0f;
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx)
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int tx = x + dx, ty = y + dy;
-            if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
-            const float gk = kG3[(dx != 0) + (dy != 0)];
-            gsum += gk;
-            vsum += gk * a.in[pix_index(g, tx, ty)].w;
-        }
-    const float var_c = vsum / gsum;
+    float var_c;
+    const bool okl = x - 1 >= 0, okr = x + 1 < g.W, oku = y - 1 >= 0, okd = y + 1 < g.H;
+    auto var_at = [&](int tx, int ty) { return a.in[pix_index(g, tx, ty)].w; };
+    if (okl && okr && oku && okd) {
+        var_c = prefilter9(var_at(x - 1, y - 1), var_at(x - 1, y), var_at(x - 1, y + 1), var_at(x, y - 1), ctr.c.w,
+                           var_at(x, y + 1), var_at(x + 1, y - 1), var_at(x + 1, y), var_at(x + 1, y + 1));
+    } else {
+        float gs = 0.25f, vs = 0.25f * ctr.c.w;
+        if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x - 1, y - 1), vs); }
+        if (okl)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x - 1, y), vs); }
+        if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x - 1, y + 1), vs); }
+        if (oku)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x, y - 1), vs); }
+        if (okd)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x, y + 1), vs); }
+        if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x + 1, y - 1), vs); }
+        if (okr)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x + 1, y), vs); }
+        if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x + 1, y + 1), vs); }
+        var_c = vs / gs;
+    }
     const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
-    const float gz = fabsf(a.nd[pix_index(g, x1, y)].w - n.w) + fabsf(a.nd[pix_index(g, x, y1)].w - n.w);
-    const Center k = make_center(c, n, var_c, gz, a.sigma_z, a.sigma_l, (float)s);
+    const float gz = fabsf(a.nd[pix_index(g, x1, y)].w - ctr.n.w) + fabsf(a.nd[pix_index(g, x, y1)].w - ctr.n.w);
+    Center<float> k;
+    CenterAux aux;
+    make_center(ctr, var_c, gz, a.sigma_z, a.sigma_l, (float)s, k, aux);
 
-    Acc acc = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    // Same grouping as the stream kernel: a pixel whose lattice index floor(y/s) is even (role A)
+    // sums its dy=-2 row apart from the other four rows, an odd one (role B) its dy=+2 row; each
+    // group is summed dx outer / dy inner and the two groups are added at the end.
+    const int lone_dy = ((y / s) & 1) ? 2 : -2;
+    Acc<float> acc = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, lone = acc;
 #pragma unroll
     for (int dx = -2; dx <= 2; ++dx) {
 #pragma unroll
@@ -148,125 +260,154 @@ __global__ __launch_bounds__(256) void atrous_direct_kernel(AtrousArgs a)
             const int tx = x + s * dx, ty = y + s * dy;
             if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
             const size_t ti = pix_index(g, tx, ty);
-            const float4 tc = a.in[ti];
-            const float4 tn = a.nd[ti];
+            Tap t;
+            t.c = to_lrgv(a.in[ti]);
+            t.n = a.nd[ti];
             const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-            const float e0 = kLogB3[adx] + kLogB3[ady];
-            tap_accum<true>(acc, k, tc, tn, lum3(tc.x, tc.y, tc.z), e0, adx, ady, a.sigma_n);
+            if (dy == lone_dy) tap_single<true>(lone, k, aux, t, kLogB3[adx] + kLogB3[ady], adx, ady, a.sigma_n);
+            else               tap_single<true>(acc, k, aux, t, kLogB3[adx] + kLogB3[ady], adx, ady, a.sigma_n);
         }
     }
-    a.out[i] = finish(acc, c);
+    a.out[i] = finish(lone.sw + acc.sw, lone.sl + acc.sl, lone.sr + acc.sr, lone.sg + acc.sg, lone.sv + acc.sv, ctr.c);
 }
 
 // ---------------------------------------------------------------------------------- stream
-template <int S>
+// NP = row pairs per workgroup.  The 256 threads are NP groups of CW = 256/NP columns; group p
+// produces lattice rows j+2p (role A) and j+2p+1 (role B) of the step, so a step yields 2*NP rows
+// of CW pixels from a ring of NR = 2*NP + 4 staged rows.  NP = 2 halves the LDS bytes per thread
+// (8 rows for 4 output rows instead of 6 for 2), which is what lets 3 workgroups (12 waves) share
+// a CU: one wave issues at most one instruction every ~6-7 cycles, so two waves per SIMD cannot
+// saturate its VALU (tools/microbench/valu_rate).
+template <int S, int NP>
 struct StreamCfg {
-    static constexpr int BX = 256;                    // output columns per workgroup = threads
-    static constexpr int PW = BX + 4 * S;             // staged row width in pixels (halo 2S each side)
-    static constexpr int NR = 6;                      // ring: lattice rows j-2 .. j+3
+    static constexpr int CW = 256 / NP;               // output columns per workgroup
+    static constexpr int PW = CW + 4 * S;             // staged row width in pixels (halo 2S each side)
+    static constexpr int NR = 2 * NP + 4;             // ring rows: j-2 .. j+2NP+1
+    static constexpr int ADV = 2 * NP;                // lattice rows produced per step
     static constexpr int ROW_BYTES = PW * 16;
     static constexpr int PLANE_BYTES = NR * ROW_BYTES;
-    static constexpr int VAR_OFF = 2 * PLANE_BYTES;   // 4 rows of BX+2 floats: variance of rows y-1 / y+1
-    static constexpr int VAR_ROW = BX + 2;
-    static constexpr int LDS_BYTES = VAR_OFF + 4 * VAR_ROW * 4;
+    static constexpr int VAR_OFF = 2 * PLANE_BYTES;   // 4*NP rows of CW+2 floats: variance of rows y-1 / y+1
+    static constexpr int VAR_ROW = CW + 2;
+    static constexpr int LDS_BYTES = VAR_OFF + 4 * NP * VAR_ROW * 4;
+    static constexpr int TAIL = 16 * S * NP;          // float4 elements in the 4S-pixel row tails of one refill
+    static constexpr int NT = (TAIL + 255) / 256;     // tail loads per thread
+    static constexpr int WG_PER_CU = NP == 1 ? 2 : 3;
 };
 
 __device__ __forceinline__ float4 lds_f4(const unsigned char* lds, int off) { return *reinterpret_cast<const float4*>(lds + off); }
 __device__ __forceinline__ float  lds_f1(const unsigned char* lds, int off) { return *reinterpret_cast<const float*>(lds + off); }
 
-template <int S, bool EDGE>
+// Lattice rows of this workgroup are y = ybase + j*S; ybase/S is even, so j even <=> pixel role A
+// (global lattice index floor(y/S) even).  Outputs are wanted for j in [jlo, jhi); pairs (j, j+1)
+// with j even are processed from j0 = jlo & ~1, a pixel whose row falls outside [jlo, jhi) is
+// computed and dropped.  The pairing therefore depends only on (y, S), never on the row range or
+// the band decomposition: outputs are bit-identical for every decomposition.
+template <int S, int NP, bool EDGE>
 __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned char* lds, const int tid,
-                                                   const int x0, const int ybase, const int nj)
+                                                   const int x0, const int ybase, const int jlo, const int jhi)
 {
-    using C = StreamCfg<S>;
+    using C = StreamCfg<S, NP>;
     const Geom g = a.g;
-    const int x = x0 + tid;
+    const int col = tid % C::CW;                      // column inside the strip
+    const int pr = tid / C::CW;                       // row pair of this thread (wave-uniform)
+    const int x = x0 + col;
     const bool xin = !EDGE || x < g.W;
     const float* in_f = reinterpret_cast<const float*>(a.in);
     const float* nd_f = reinterpret_cast<const float*>(a.nd);
     float* var_lds = reinterpret_cast<float*>(lds + C::VAR_OFF);
 
-    // ---- register prefetch state: two lattice rows (color, nd), and for the next output pair the
-    // variance of rows y-1 / y+1 (3x3 prefilter) and z of row y+1 (depth gradient)
-    float4 pc[2], pn[2], pe;
+    // ---- register prefetch state: two lattice rows (color, nd) + row tails, and for the next
+    // output pair the variance of rows y-1 / y+1 (3x3 prefilter) and z of row y+1 (depth gradient)
+    float4 pc[2], pn[2], pe[C::NT];
     float pvu[2], pvd[2], pzd[2], pvh = 0.0f;
     float zd_cur[2] = { 0.0f, 0.0f };
 
     // Global addresses are formed as (wave-uniform row base) + (lane index): the uniform part
-    // stays in SGPRs (global_load ... saddr), only tid*16 lives in a VGPR.
+    // stays in SGPRs (global_load ... saddr), only the lane offset lives in a VGPR.
     auto row_base = [&](const int y, const int xs) -> long long {
         return (long long)(y - g.buf_row0) * (long long)g.W + (long long)xs;
     };
-    // A staged row is BX + 4S pixels.  Threads load pixel `tid` of both rows and both planes; the
-    // 4S-pixel tails of the 2 rows x 2 planes (16S float4 in all) are spread over lanes < 16S as
-    // ONE extra load per lane: tail element e -> row (e/4S)>>1, plane (e/4S)&1, column BX + e%4S.
-    const int e_sel = tid / (4 * S), e_col = C::BX + tid % (4 * S);
-    const bool e_act = tid < 16 * S;
-    auto load_rows = [&](const int j0) {
+    // rows outside the frame are zero-filled and their taps masked; rows inside the frame but
+    // outside the buffer can only be asked for by a dropped pixel and are zero-filled too
+    auto row_in_buffer = [&](const int y) { return y >= max(g.buf_row0, 0) && y < min(g.buf_row0 + g.buf_rows, g.H); };
+    auto slot_of = [&](const int j) { return (j + 4 * C::NR) % C::NR; };        // j >= -2
+
+    // A refill brings ADV rows (jb .. jb+ADV-1).  Thread (pr, col) loads pixel `col` of rows
+    // jb+2pr, jb+2pr+1 of both planes; the 4S-pixel tails of the ADV rows x 2 planes (TAIL float4
+    // in all) are spread over the threads: tail element e -> row (e/4S)>>1, plane (e/4S)&1,
+    // column CW + e%4S.
+    auto load_rows = [&](const int jb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int j = j0 + i;
-            const int y = ybase + j * S;
-            const bool rowok = (j <= nj + 1) && (!EDGE || (y >= 0 && y < g.H));
-            bool act = rowok;
-            if (EDGE) act = act && x - 2 * S >= 0 && x - 2 * S < g.W;
+            const int y = ybase + (jb + 2 * pr + i) * S;
+            bool act = !EDGE || (row_in_buffer(y) && x - 2 * S >= 0 && x - 2 * S < g.W);
             float4 vc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = vc;
             if (act) {
                 const long long o = row_base(y, x0 - 2 * S);
-                vc = (a.in + o)[tid];
-                vn = (a.nd + o)[tid];
+                vc = (a.in + o)[col];
+                vn = (a.nd + o)[col];
             }
             pc[i] = vc;
             pn[i] = vn;
         }
-        {
-            const int j = j0 + (e_sel >> 1);
-            const int y = ybase + j * S;
-            const int gx = x0 - 2 * S + e_col;
-            bool act = e_act && (j <= nj + 1);
-            if (EDGE) act = act && y >= 0 && y < g.H && gx >= 0 && gx < g.W;
+#pragma unroll
+        for (int q = 0; q < C::NT; ++q) {
+            const int e = tid + q * 256;
+            const int sel = e / (4 * S);
+            const int y = ybase + (jb + (sel >> 1)) * S;
+            const int gx = x0 - 2 * S + C::CW + e % (4 * S);
+            bool act = e < C::TAIL;
+            if (EDGE) act = act && row_in_buffer(y) && gx >= 0 && gx < g.W;
             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (act) {
-                const float4* plane = (e_sel & 1) ? a.nd : a.in;
+                const float4* plane = (sel & 1) ? a.nd : a.in;
                 v = plane[(size_t)(y - g.buf_row0) * (size_t)g.W + (size_t)gx];
             }
-            pe = v;
+            pe[q] = v;
         }
     };
-    auto store_rows = [&](const int j0) {
+    // colour is staged as (lum, r, g, var): luminance once per staged pixel instead of once per tap
+    auto store_rows = [&](const int jb) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int slot = (j0 + i + 6) % 6;
-            const int off = slot * C::ROW_BYTES + tid * 16;
-            *reinterpret_cast<float4*>(lds + off) = pc[i];
+            const int off = slot_of(jb + 2 * pr + i) * C::ROW_BYTES + col * 16;
+            *reinterpret_cast<float4*>(lds + off) = to_lrgv(pc[i]);
             *reinterpret_cast<float4*>(lds + C::PLANE_BYTES + off) = pn[i];
         }
-        if (e_act) {
-            const int slot = (j0 + (e_sel >> 1) + 6) % 6;
-            const int off = ((e_sel & 1) ? C::PLANE_BYTES : 0) + slot * C::ROW_BYTES + e_col * 16;
-            *reinterpret_cast<float4*>(lds + off) = pe;
+#pragma unroll
+        for (int q = 0; q < C::NT; ++q) {
+            const int e = tid + q * 256;
+            if (e < C::TAIL) {
+                const int sel = e / (4 * S);
+                const bool is_nd = (sel & 1) != 0;
+                const int off = (is_nd ? C::PLANE_BYTES : 0) + slot_of(jb + (sel >> 1)) * C::ROW_BYTES + (C::CW + e % (4 * S)) * 16;
+                *reinterpret_cast<float4*>(lds + off) = is_nd ? pe[q] : to_lrgv(pe[q]);
+            }
         }
     };
+    // aux rows of the outputs of step jo: thread (pr, col) serves its own two pixels
     auto load_aux = [&](const int jo) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int y = ybase + (jo + i) * S;
-            const bool rowok = (jo + i) < nj && xin;
+            const int jj = jo + 2 * pr + i;
+            const int y = ybase + jj * S;
+            const bool rowok = jj >= jlo && jj < jhi && xin;
             float vu = 0.0f, vd = 0.0f, zd = 0.0f;
             if (rowok) {
-                if (!EDGE || y - 1 >= 0) vu = (in_f + row_base(y - 1, x0) * 4 + 3)[tid * 4];
-                if (!EDGE || y + 1 < g.H) vd = (in_f + row_base(y + 1, x0) * 4 + 3)[tid * 4];
+                if (!EDGE || y - 1 >= 0) vu = (in_f + row_base(y - 1, x0) * 4 + 3)[col * 4];
+                if (!EDGE || y + 1 < g.H) vd = (in_f + row_base(y + 1, x0) * 4 + 3)[col * 4];
                 const int yz = EDGE ? min(y + 1, g.H - 1) : y + 1;
-                zd = (nd_f + row_base(yz, x0) * 4 + 3)[tid * 4];
+                zd = (nd_f + row_base(yz, x0) * 4 + 3)[col * 4];
             }
             pvu[i] = vu; pvd[i] = vd; pzd[i] = zd;
         }
         pvh = 0.0f;
-        if (tid < 8) {   // halo columns x0-1 and x0+BX of the four variance rows
+        if (tid < 8 * NP) {   // halo columns x0-1 and x0+CW of the 4*NP variance rows
             const int ii = tid >> 2, ud = (tid >> 1) & 1, side = tid & 1;
-            const int yy = ybase + (jo + ii) * S + (ud ? 1 : -1);
-            const int xx = side ? x0 + C::BX : x0 - 1;
-            bool ok = (jo + ii) < nj;
+            const int jj = jo + ii;
+            const int yy = ybase + jj * S + (ud ? 1 : -1);
+            const int xx = side ? x0 + C::CW : x0 - 1;
+            bool ok = jj >= jlo && jj < jhi;
             if (EDGE) ok = ok && yy >= 0 && yy < g.H && xx >= 0 && xx < g.W;
             if (ok) pvh = in_f[((size_t)(yy - g.buf_row0) * (size_t)g.W + (size_t)xx) * 4 + 3];
         }
@@ -274,67 +415,74 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     auto store_aux = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            var_lds[(i * 2 + 0) * C::VAR_ROW + tid + 1] = pvu[i];
-            var_lds[(i * 2 + 1) * C::VAR_ROW + tid + 1] = pvd[i];
+            var_lds[((2 * pr + i) * 2 + 0) * C::VAR_ROW + col + 1] = pvu[i];
+            var_lds[((2 * pr + i) * 2 + 1) * C::VAR_ROW + col + 1] = pvd[i];
             zd_cur[i] = pzd[i];
         }
-        if (tid < 8) {
+        if (tid < 8 * NP) {
             const int ii = tid >> 2, ud = (tid >> 1) & 1, side = tid & 1;
-            var_lds[(ii * 2 + ud) * C::VAR_ROW + (side ? C::BX + 1 : 0)] = pvh;
+            var_lds[(ii * 2 + ud) * C::VAR_ROW + (side ? C::CW + 1 : 0)] = pvh;
         }
     };
 
     // ---- per-pixel setup (A.A.1 prefilter, depth gradient) from the staged data
-    auto setup = [&](const int i, const int y, const int rb_center, const float4 c, const float4 n) -> Center {
+    auto setup = [&](const int i, const int y, const int rb_center, const Tap& t, Center<float>& k, CenterAux& aux) {
         const int ccol = rb_center + 2 * S * 16;      // byte offset of the centre pixel in the color plane
-        const float* vu = var_lds + (i * 2 + 0) * C::VAR_ROW + tid;     // [0..2] = x-1, x, x+1 of row y-1
-        const float* vd = var_lds + (i * 2 + 1) * C::VAR_ROW + tid;
+        const float* vu = var_lds + ((2 * pr + i) * 2 + 0) * C::VAR_ROW + col;     // [0..2] = x-1, x, x+1 of row y-1
+        const float* vd = var_lds + ((2 * pr + i) * 2 + 1) * C::VAR_ROW + col;
         const float v_l = lds_f1(lds, ccol - 16 + 12), v_r = lds_f1(lds, ccol + 16 + 12);
         float var_c;
-        if (!EDGE) {
-            // oracle order: dx outer, dy inner; weights sum to exactly 1
-            float vs = kG3[2] * vu[0];
-            vs += kG3[1] * v_l;  vs += kG3[2] * vd[0];
-            vs += kG3[1] * vu[1]; vs += kG3[0] * c.w; vs += kG3[1] * vd[1];
-            vs += kG3[2] * vu[2]; vs += kG3[1] * v_r; vs += kG3[2] * vd[2];
-            var_c = vs;
+        bool interior = true;
+        bool okl = true, okr = true, oku = true, okd = true;
+        if (EDGE) {
+            okl = x - 1 >= 0; okr = x + 1 < g.W; oku = y - 1 >= 0; okd = y + 1 < g.H;
+            interior = okl && okr && oku && okd;
+        }
+        if (interior) {
+            var_c = prefilter9(vu[0], v_l, vd[0], vu[1], t.c.w, vd[1], vu[2], v_r, vd[2]);
         } else {
-            const bool okl = x - 1 >= 0, okr = x + 1 < g.W, oku = y - 1 >= 0, okd = y + 1 < g.H;
-            float gs = 0.0f, vs = 0.0f;
-            if (okl && oku) { gs += kG3[2]; vs += kG3[2] * vu[0]; }
-            if (okl)        { gs += kG3[1]; vs += kG3[1] * v_l; }
-            if (okl && okd) { gs += kG3[2]; vs += kG3[2] * vd[0]; }
-            if (oku)        { gs += kG3[1]; vs += kG3[1] * vu[1]; }
-            gs += kG3[0]; vs += kG3[0] * c.w;
-            if (okd)        { gs += kG3[1]; vs += kG3[1] * vd[1]; }
-            if (okr && oku) { gs += kG3[2]; vs += kG3[2] * vu[2]; }
-            if (okr)        { gs += kG3[1]; vs += kG3[1] * v_r; }
-            if (okr && okd) { gs += kG3[2]; vs += kG3[2] * vd[2]; }
+            float gs = 0.25f, vs = 0.25f * t.c.w;
+            if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, vu[0], vs); }
+            if (okl)        { gs += 0.125f;  vs = fma_(0.125f, v_l, vs); }
+            if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, vd[0], vs); }
+            if (oku)        { gs += 0.125f;  vs = fma_(0.125f, vu[1], vs); }
+            if (okd)        { gs += 0.125f;  vs = fma_(0.125f, vd[1], vs); }
+            if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, vu[2], vs); }
+            if (okr)        { gs += 0.125f;  vs = fma_(0.125f, v_r, vs); }
+            if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, vd[2], vs); }
             var_c = vs / gs;
         }
         float zr = lds_f1(lds, C::PLANE_BYTES + ccol + 16 + 12);
-        if (EDGE && !(x + 1 < g.W)) zr = n.w;
-        const float gz = fabsf(zr - n.w) + fabsf(zd_cur[i] - n.w);
-        return make_center(c, n, var_c, gz, a.sigma_z, a.sigma_l, (float)S);
+        if (EDGE && !okr) zr = t.n.w;
+        const float gz = fabsf(zr - t.n.w) + fabsf(zd_cur[i] - t.n.w);
+        make_center(t, var_c, gz, a.sigma_z, a.sigma_l, (float)S, k, aux);
     };
 
-    // ---- one step: outputs at lattice rows j and j+1
+    // ---- one step: this thread's outputs are lattice rows jw (A) and jw+1 (B), jw = j + 2*pr
     auto compute = [&](const int j) {
+        const int jw = j + 2 * pr;
         int rb[6];
         {
-            int slot = (j + 4) % 6;                    // ring slot of lattice row j-2
+            int slot = slot_of(jw - 2);
 #pragma unroll
             for (int tr = 0; tr < 6; ++tr) {
-                rb[tr] = slot * C::ROW_BYTES + tid * 16;
-                slot = slot == 5 ? 0 : slot + 1;
+                rb[tr] = slot * C::ROW_BYTES + col * 16;
+                slot = slot == C::NR - 1 ? 0 : slot + 1;
             }
         }
-        const int yA = ybase + j * S, yB = yA + S;
-        const float4 cA = lds_f4(lds, rb[2] + 2 * S * 16), nA = lds_f4(lds, C::PLANE_BYTES + rb[2] + 2 * S * 16);
-        const float4 cB = lds_f4(lds, rb[3] + 2 * S * 16), nB = lds_f4(lds, C::PLANE_BYTES + rb[3] + 2 * S * 16);
-        const Center kA = setup(0, yA, rb[2], cA, nA);
-        const Center kB = setup(1, yB, rb[3], cB, nB);
-        Acc sA = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, sB = sA;
+        const int yA = ybase + jw * S, yB = yA + S;
+        Tap cA, cB;
+        cA.c = lds_f4(lds, rb[2] + 2 * S * 16); cA.n = lds_f4(lds, C::PLANE_BYTES + rb[2] + 2 * S * 16);
+        cB.c = lds_f4(lds, rb[3] + 2 * S * 16); cB.n = lds_f4(lds, C::PLANE_BYTES + rb[3] + 2 * S * 16);
+        Center<float> kA, kB;
+        CenterAux xA, xB;
+        setup(0, yA, rb[2], cA, kA, xA);
+        setup(1, yB, rb[3], cB, kB, xB);
+        const Center<f2> kAB = pack(kA, kB);
+        kA = Center<float>{ kAB.nx.x, kAB.ny.x, kAB.nz.x, kAB.z.x, kAB.lum.x, kAB.il.x };   // lanes, not copies
+        kB = Center<float>{ kAB.nx.y, kAB.ny.y, kAB.nz.y, kAB.z.y, kAB.lum.y, kAB.il.y };
+        Acc<f2> sAB = { f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
+        Acc<float> sA = { 0, 0, 0, 0, 0 }, sB = sA;      // rows only one of the two pixels taps (tr = 0 / tr = 5)
 
         bool rowv[6];
 #pragma unroll
@@ -343,89 +491,95 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             rowv[tr] = !EDGE || (yy >= 0 && yy < g.H);
         }
         // a wave takes the cheaper path when none of its centres has a zero normal
-        const bool any_zero = __builtin_amdgcn_ballot_w64(kA.zero || kB.zero) != 0ull;
+        const bool any_zero = __builtin_amdgcn_ballot_w64(xA.zero || xB.zero) != 0ull;
 
-        // One tap column (fixed dx, the six ring rows) is fetched while the previous column is
-        // being weighted; sched_barrier keeps the compiler from hoisting all 60 ds_read_b128 of a
-        // step to the top (which needs > 256 VGPRs and spills).
-        auto load_col = [&](const int dxi, float4 (&tc)[6], float4 (&tn)[6]) {
+        // The 30 taps of a step are walked as 15 groups of two window rows (dx outer, rows inner):
+        // the ds_read_b128 of group g+1 are issued before group g is weighted, and a scheduling fence
+        // per group keeps the compiler from hoisting every read of the step to the top (that needs
+        // more VGPRs than 3 waves per SIMD leave: 168).
+        auto load_grp = [&](const int grp, Tap (&t)[2]) {
+            const int dxi = grp / 3, tr0 = (grp % 3) * 2;
 #pragma unroll
-            for (int tr = 0; tr < 6; ++tr) {
-                const int off = rb[tr] + (2 * S + (dxi - 2) * S) * 16;
-                tc[tr] = lds_f4(lds, off);
-                tn[tr] = lds_f4(lds, C::PLANE_BYTES + off);
+            for (int q = 0; q < 2; ++q) {
+                const int off = rb[tr0 + q] + (2 * S + (dxi - 2) * S) * 16;
+                t[q].c = lds_f4(lds, off);
+                t[q].n = lds_f4(lds, C::PLANE_BYTES + off);
             }
         };
         auto taps = [&](auto zero_aware) {
             constexpr bool ZA = decltype(zero_aware)::value;
-            auto weigh_col = [&](const int dxi, const float4 (&tc)[6], const float4 (&tn)[6]) {
+            // per-output order stays dx outer / dy inner: A sees rows 0..4 as dy=-2..2, B rows 1..5
+            auto weigh_grp = [&](const int grp, const Tap (&t)[2]) {
+                const int dxi = grp / 3, tr0 = (grp % 3) * 2;
                 const int dx = dxi - 2;
                 const int adx = dx < 0 ? -dx : dx;
                 const bool colv = !EDGE || (x + dx * S >= 0 && x + dx * S < g.W);
 #pragma unroll
-                for (int tr = 0; tr < 6; ++tr) {
-                    const float tl = lum3(tc[tr].x, tc[tr].y, tc[tr].z);
+                for (int q = 0; q < 2; ++q) {
+                    const int tr = tr0 + q;
                     const float ecol = (!EDGE || (colv && rowv[tr])) ? kLogB3[adx] : kNegInf;
-                    if (tr <= 4) {
-                        const int dy = tr - 2, ady = dy < 0 ? -dy : dy;
-                        tap_accum<ZA>(sA, kA, tc[tr], tn[tr], tl, ecol + kLogB3[ady], adx, ady, a.sigma_n);
-                    }
-                    if (tr >= 1) {
-                        const int dy = tr - 3, ady = dy < 0 ? -dy : dy;
-                        tap_accum<ZA>(sB, kB, tc[tr], tn[tr], tl, ecol + kLogB3[ady], adx, ady, a.sigma_n);
+                    const int dyA = tr - 2, dyB = tr - 3;
+                    const int adyA = dyA < 0 ? -dyA : dyA, adyB = dyB < 0 ? -dyB : dyB;
+                    if (tr == 0) {
+                        tap_single<ZA>(sA, kA, xA, t[q], ecol + kLogB3[adyA], adx, adyA, a.sigma_n);
+                    } else if (tr == 5) {
+                        tap_single<ZA>(sB, kB, xB, t[q], ecol + kLogB3[adyB], adx, adyB, a.sigma_n);
+                    } else {
+                        const f2 e0 = { ecol + kLogB3[adyA], ecol + kLogB3[adyB] };
+                        tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0, adx, adyA, adyB, a.sigma_n);
                     }
                 }
             };
-#if RMD_ATROUS_COLBUF == 2
-            float4 c0[6], n0[6], c1[6], n1[6];
-            load_col(0, c0, n0);
-            __builtin_amdgcn_sched_barrier(0);
+            Tap t0[2], t1[2];
+            load_grp(0, t0);
 #pragma unroll
-            for (int dxi = 0; dxi < 5; ++dxi) {
-                if (dxi & 1) { if (dxi < 4) load_col(dxi + 1, c0, n0); weigh_col(dxi, c1, n1); }
-                else         { if (dxi < 4) load_col(dxi + 1, c1, n1); weigh_col(dxi, c0, n0); }
+            for (int grp = 0; grp < 15; ++grp) {
+                if (grp & 1) { if (grp < 14) load_grp(grp + 1, t0); weigh_grp(grp, t1); }
+                else         { if (grp < 14) load_grp(grp + 1, t1); weigh_grp(grp, t0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
-#else
-#pragma unroll
-            for (int dxi = 0; dxi < 5; ++dxi) {
-                float4 c0[6], n0[6];
-                load_col(dxi, c0, n0);
-                weigh_col(dxi, c0, n0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#endif
         };
         if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
 
+        // Per-pixel sums = (row only this pixel taps: dy=-2 for role A, dy=+2 for role B) + (the four
+        // rows shared with its partner), each summed dx outer / dy inner.  The direct kernel groups
+        // its 25 taps the same way, so the two variants stay bit-identical.
         if (xin) {
-            (a.out + row_base(yA, x0))[tid] = finish(sA, cA);
-            if (j + 1 < nj) (a.out + row_base(yB, x0))[tid] = finish(sB, cB);
+            if (jw >= jlo && jw < jhi)
+                (a.out + row_base(yA, x0))[col] = finish(sA.sw + sAB.sw.x, sA.sl + sAB.sl.x, sA.sr + sAB.sr.x, sA.sg + sAB.sg.x,
+                                                         sA.sv + sAB.sv.x, cA.c);
+            if (jw + 1 >= jlo && jw + 1 < jhi)
+                (a.out + row_base(yB, x0))[col] = finish(sB.sw + sAB.sw.y, sB.sl + sAB.sl.y, sB.sr + sAB.sr.y,
+                                                         sB.sg + sAB.sg.y, sB.sv + sAB.sv.y, cB.c);
         }
     };
 
-    // ---- prologue: lattice rows -2..3 and the aux rows of the first pair
-    load_rows(-2); store_rows(-2);
-    load_rows(0);  store_rows(0);
-    load_rows(2);  load_aux(0);
-    store_rows(2); store_aux();
+    // ---- prologue: ring rows j0-2 .. j0-2+NR-1 (NR/ADV refills) and the aux rows of the first step
+    const int j0 = jlo & ~1;
+#pragma unroll
+    for (int q = 0; q < C::NR / C::ADV; ++q) {
+        load_rows(j0 - 2 + q * C::ADV);
+        if (q == C::NR / C::ADV - 1) load_aux(j0);
+        store_rows(j0 - 2 + q * C::ADV);
+    }
+    store_aux();
     __syncthreads();
 
-    for (int j = 0; j < nj; j += 2) {
-        const bool more = j + 2 < nj;
-        if (more) { load_rows(j + 4); load_aux(j + 2); }     // in flight during compute
+    for (int j = j0; j < jhi; j += C::ADV) {
+        const bool more = j + C::ADV < jhi;
+        if (more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute
         compute(j);
         if (!more) break;
-        __syncthreads();                                     // every wave is done reading rows j-2, j-1
-        store_rows(j + 4); store_aux();
+        __syncthreads();                                     // every wave is done reading the ADV oldest rows
+        store_rows(j - 2 + C::NR); store_aux();
         __syncthreads();
     }
 }
 
-template <int S>
-__global__ __launch_bounds__(256, 2) void atrous_stream_kernel(AtrousArgs a)
+template <int S, int NP>
+__global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(AtrousArgs a)
 {
-    using C = StreamCfg<S>;
+    using C = StreamCfg<S, NP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char atrous_lds[];
     const int tid = threadIdx.x;
     // XCD-aware remap: workgroups pid, pid+8, ... share an XCD (round-robin dispatch), give each
@@ -435,43 +589,62 @@ __global__ __launch_bounds__(256, 2) void atrous_stream_kernel(AtrousArgs a)
     if (L >= a.nblocks) return;
     const int r = L % S, t = L / S;
     const int strip = t % a.nstrips, band = t / a.nstrips;
-    const int x0 = strip * C::BX;
-    const int yb = a.row0 + band * a.band_h;
-    const int ye = min(yb + a.band_h, a.row1);
+    const int x0 = strip * C::CW;
+    // bands are aligned to multiples of band_h (a multiple of 2S*NP) in GLOBAL rows
+    const int yb = (a.row0 / a.band_h + band) * a.band_h;
+    const int lo = max(yb, a.row0), hi = min(yb + a.band_h, a.row1);
     const int ybase = yb + r;
-    if (ybase >= ye) return;
-    const int nj = (ye - ybase + S - 1) / S;
-    const bool edge = (x0 - 2 * S < 0) || (x0 + C::BX + 2 * S > a.g.W) || (ybase - 2 * S < 0) ||
-                      (ybase + (nj + 1) * S >= a.g.H);
-    if (edge) atrous_stream_body<S, true>(a, atrous_lds, tid, x0, ybase, nj);
-    else      atrous_stream_body<S, false>(a, atrous_lds, tid, x0, ybase, nj);
+    const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
+    const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;      // exclusive
+    if (jlo >= jhi) return;
+    // lattice rows touched: j0-2 .. j0 + nsteps*ADV + 1
+    const int j0 = jlo & ~1;
+    const int nsteps = (jhi - j0 + C::ADV - 1) / C::ADV;
+    const int ytop = ybase + (j0 - 2) * S, ybot = ybase + (j0 + nsteps * C::ADV + 1) * S;
+    const int blo = max(a.g.buf_row0, 0), bhi = min(a.g.buf_row0 + a.g.buf_rows, a.g.H);
+    const bool edge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W) || ytop < blo || ybot >= bhi;
+    if (edge) atrous_stream_body<S, NP, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+    else      atrous_stream_body<S, NP, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
 }
 
-template <int S>
+template <int S, int NP>
 static int launch_stream(AtrousArgs a, hipStream_t stream)
 {
-    using C = StreamCfg<S>;
+    using C = StreamCfg<S, NP>;
     static bool attr_done = false;
     if (!attr_done) {
-        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S>),
+        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_done = true;
     }
     const int rows = a.row1 - a.row0;
-    a.nstrips = (a.g.W + C::BX - 1) / C::BX;
-    // one resident wave of workgroups: 2 per CU (LDS-limited) x 256 CUs
+    a.nstrips = (a.g.W + C::CW - 1) / C::CW;
+    // one resident wave of workgroups: WG_PER_CU per CU (LDS-limited) x 256 CUs
     const int per_band = a.nstrips * S;
-    int nb = (2 * kCus) / per_band;
+    int nb = (C::WG_PER_CU * kCus) / per_band;
     if (nb < 1) nb = 1;
     int bh = (rows + nb - 1) / nb;
-    bh = ((bh + 2 * S - 1) / (2 * S)) * (2 * S);       // whole output pairs per lattice
+    const int unit = S * C::ADV;                        // whole steps per lattice
+    bh = ((bh + unit - 1) / unit) * unit;
     a.band_h = bh;
-    const int nbands = (rows + bh - 1) / bh;
+    const int nbands = (a.row1 - 1) / bh - a.row0 / bh + 1;     // bands are globally aligned
     a.nblocks = nbands * per_band;
     a.per_xcd = (a.nblocks + kXcds - 1) / kXcds;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S>), dim3(a.per_xcd * kXcds), dim3(C::BX), C::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S, NP>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES, stream, a);
     RMD_LAUNCH_CHECK("atrous_stream_kernel");
     return RMD_OK;
+}
+
+template <int NP>
+static int launch_stream_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
+{
+    switch (iteration) {
+        case 0: return launch_stream<1, NP>(a, stream);
+        case 1: return launch_stream<2, NP>(a, stream);
+        case 2: return launch_stream<4, NP>(a, stream);
+        case 3: return launch_stream<8, NP>(a, stream);
+        default: return launch_stream<16, NP>(a, stream);
+    }
 }
 
 }  // namespace rmd
@@ -502,17 +675,11 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     a.band_h = a.nstrips = a.nblocks = a.per_xcd = 0;
 
     int variant = p->atrous_variant;
-    if (variant == 0) variant = (iteration <= 4) ? 2 : 1;
-    if (variant == 2 && iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variant covers iterations 0..4");
-    if (variant == 2) {
-        switch (iteration) {
-            case 0: return launch_stream<1>(a, as_stream(stream));
-            case 1: return launch_stream<2>(a, as_stream(stream));
-            case 2: return launch_stream<4>(a, as_stream(stream));
-            case 3: return launch_stream<8>(a, as_stream(stream));
-            default: return launch_stream<16>(a, as_stream(stream));
-        }
-    }
+    if (variant == 0) variant = (iteration <= 4) ? 3 : 1;
+    if ((variant == 2 || variant == 3) && iteration > 4)
+        return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
+    if (variant == 2) return launch_stream_iter<1>(iteration, a, as_stream(stream));   // 256 columns x 1 row pair
+    if (variant == 3) return launch_stream_iter<2>(iteration, a, as_stream(stream));   // 128 columns x 2 row pairs
     if (variant != 1) return fail(RMD_E_PARAM, "rmd_svgf_atrous: unknown atrous_variant %d", p->atrous_variant);
     dim3 grid((f->width + 63) / 64, (row1 - row0 + 3) / 4);
     hipLaunchKernelGGL(atrous_direct_kernel, grid, dim3(256), 0, as_stream(stream), a);

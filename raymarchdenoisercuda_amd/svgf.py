@@ -117,7 +117,8 @@ class SvgfDenoiser:
     global rows [buf_row0, buf_row0+buf_rows); `denoise` produces rows [row0,row1).
     """
 
-    def __init__(self, width, height, buf_row0=0, buf_rows=None, params=None, device="cuda", debug=False):
+    def __init__(self, width, height, buf_row0=0, buf_rows=None, params=None, device="cuda", debug=False,
+                 collect_stats=False):
         self.width, self.height = width, height
         self.buf_row0 = buf_row0
         self.buf_rows = height if buf_rows is None else buf_rows
@@ -132,7 +133,8 @@ class SvgfDenoiser:
         self.t_color, self.v_color = plane(), plane()
         self.ping = [plane(), plane()]
         self.t_debug = torch.zeros((self.buf_rows, width, 4), dtype=torch.int32, device=device) if debug else None
-        self.stats = torch.zeros(4, dtype=torch.float32, device=device)
+        # frame statistics accumulated by the V pass (diagnostics; costs atomics, so opt-in)
+        self.stats = torch.zeros(4, dtype=torch.float32, device=device) if collect_stats else None
         self.cur = 0
         self.has_history = False
         self.prev_nd = None
