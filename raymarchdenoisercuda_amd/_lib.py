@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401  (device allocator for the host mirror; imported here for load order)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librmd.so")
+# RMD_LIB_PATH selects an alternative build of the same library (kernel tuning experiments only)
+LIB_PATH = os.environ.get("RMD_LIB_PATH") or os.path.join(_HERE, "lib", "librmd.so")
 
 
 class RmdError(RuntimeError):

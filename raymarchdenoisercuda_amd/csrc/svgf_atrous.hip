@@ -40,6 +40,10 @@ namespace rmd {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+#ifndef RMD_ATROUS_GROUP_ROWS
+#define RMD_ATROUS_GROUP_ROWS 2   // window rows per scheduling group of the tap loop (1, 2, 3 or 6)
+#endif
+
 struct AtrousArgs {
     Geom g;
     const float4* in; const float4* nd; float4* out;
@@ -133,29 +137,28 @@ __device__ __forceinline__ Center<f2> pack(const Center<float> a, const Center<f
     return k;
 }
 
-// The part of a tap weight that is the same code for one pixel and for the pair:
-// returns e = e0 + sigma_n*log2(clamp01(n_p.n_t)), and the signed depth / luminance differences.
+// clamp01(n_p . n_t): the same three operations for one pixel (float) and for the pair (f2)
 template <class T>
-__device__ __forceinline__ T tap_normal_term(const Center<T>& k, const Tap& t, T e0, float sigma_n, T& dz, T& dl)
+__device__ __forceinline__ T tap_cosine(const Center<T>& k, const Tap& t)
 {
     T d = k.nx * bc(t.n.x, T{});
     d = fma_(k.ny, bc(t.n.y, T{}), d);
-    d = clamp01(fma_(k.nz, bc(t.n.z, T{}), d));
-    dz = k.z - bc(t.n.w, T{});
-    dl = k.lum - bc(t.c.x, T{});
-    return fma_(bc(sigma_n, T{}), log2_(d), e0);
+    return clamp01(fma_(k.nz, bc(t.n.z, T{}), d));
 }
 
-// One lane's edge terms (abs / neg are free source modifiers of v_fma_f32).
+// One pixel's exponent, scalar on purpose: v_fma_f32 takes |.| and - as free source modifiers and
+// e0 as a literal (packed f32 has neither, and a packed e0 would need a VGPR pair per tap):
+//   e = e0 + sigma_n*log2(cos) - |z_p - z_t|*iz - |l_p - l_t|*il
 template <bool ZERO_AWARE>
-__device__ __forceinline__ float tap_edge_terms(float e, float e0, float dz, float dl, float il, const CenterAux& x,
-                                                bool tap_zero, int adx, int ady)
+__device__ __forceinline__ float tap_exponent(float cosine, float e0, float sigma_n, float zp, float lp, float il,
+                                              const CenterAux& x, const Tap& t, bool tap_zero, int adx, int ady)
 {
+    float e = fma_(sigma_n, log2_(cosine), e0);
     if (ZERO_AWARE) {   // Appendix A.A.2: both normals zero => w_n = 1, exactly one zero => 0
         if (x.zero) e = tap_zero ? e0 : kNegInf;
     }
-    if (adx | ady) e = fma_(-fabsf(dz), x.iz[len_class(adx, ady)], e);
-    return fma_(-fabsf(dl), il, e);
+    if (adx | ady) e = fma_(-fabsf(zp - t.n.w), x.iz[len_class(adx, ady)], e);
+    return fma_(-fabsf(lp - t.c.x), il, e);
 }
 
 template <class T>
@@ -173,28 +176,25 @@ template <bool ZERO_AWARE>
 __device__ __forceinline__ void tap_single(Acc<float>& s, const Center<float>& k, const CenterAux& x, const Tap& t,
                                            float e0, int adx, int ady, float sigma_n)
 {
-    float dz, dl;
-    float e = tap_normal_term<float>(k, t, e0, sigma_n, dz, dl);
-    e = tap_edge_terms<ZERO_AWARE>(e, e0, dz, dl, k.il, x, ZERO_AWARE && is_zero3(t.n), adx, ady);
+    const float e = tap_exponent<ZERO_AWARE>(tap_cosine<float>(k, t), e0, sigma_n, k.z, k.lum, k.il, x, t,
+                                             ZERO_AWARE && is_zero3(t.n), adx, ady);
     tap_accumulate<float>(s, exp2_(e), t);
 }
 
-// the (A,B) pair sharing one tap: dyA / dyB are the tap's row offsets seen from A and from B
+// the (A,B) pair sharing one tap: adyA / adyB are the tap's |row offset| seen from A and from B.
+// Cosine and accumulation are packed (v_pk_*), the exponents scalar; the empty asm keeps the
+// optimizer from re-vectorising the exponents (it would gather iz[] pairs through scratch).
 template <bool ZERO_AWARE>
 __device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const CenterAux& xa, const CenterAux& xb,
-                                         const Tap& t, f2 e0, int adx, int adyA, int adyB, float sigma_n)
+                                         const Tap& t, float e0A, float e0B, int adx, int adyA, int adyB, float sigma_n)
 {
-    f2 dz, dl;
-    const f2 e = tap_normal_term<f2>(k, t, e0, sigma_n, dz, dl);
+    const f2 c = tap_cosine<f2>(k, t);
     const bool tz = ZERO_AWARE && is_zero3(t.n);
-    // The edge terms stay scalar (|.| and - are free source modifiers of v_fma_f32, packed f32 has
-    // no abs).  The empty asm keeps the optimizer from re-vectorising them: it would gather the
-    // per-pixel iz[] constants into <2 x float> through a scratch array.
-    float ex = e.x, ey = e.y;
-    asm("" : "+v"(ex), "+v"(ey));
-    ex = tap_edge_terms<ZERO_AWARE>(ex, e0.x, dz.x, dl.x, k.il.x, xa, tz, adx, adyA);
-    ey = tap_edge_terms<ZERO_AWARE>(ey, e0.y, dz.y, dl.y, k.il.y, xb, tz, adx, adyB);
-    tap_accumulate<f2>(s, f2{ exp2_(ex), exp2_(ey) }, t);
+    float ca = c.x, cb = c.y;
+    asm("" : "+v"(ca), "+v"(cb));
+    const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, k.z.x, k.lum.x, k.il.x, xa, t, tz, adx, adyA);
+    const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, k.z.y, k.lum.y, k.il.y, xb, t, tz, adx, adyB);
+    tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t);
 }
 
 // A.A.3.  c = the centre in (lum, r, g, var) form.
@@ -493,14 +493,15 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         // a wave takes the cheaper path when none of its centres has a zero normal
         const bool any_zero = __builtin_amdgcn_ballot_w64(xA.zero || xB.zero) != 0ull;
 
-        // The 30 taps of a step are walked as 15 groups of two window rows (dx outer, rows inner):
+        // The 30 taps of a step are walked in groups of GR window rows (dx outer, rows inner):
         // the ds_read_b128 of group g+1 are issued before group g is weighted, and a scheduling fence
         // per group keeps the compiler from hoisting every read of the step to the top (that needs
         // more VGPRs than 3 waves per SIMD leave: 168).
-        auto load_grp = [&](const int grp, Tap (&t)[2]) {
-            const int dxi = grp / 3, tr0 = (grp % 3) * 2;
+        constexpr int GR = RMD_ATROUS_GROUP_ROWS, NG = 5 * (6 / GR);
+        auto load_grp = [&](const int grp, Tap (&t)[GR]) {
+            const int dxi = grp / (6 / GR), tr0 = (grp % (6 / GR)) * GR;
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < GR; ++q) {
                 const int off = rb[tr0 + q] + (2 * S + (dxi - 2) * S) * 16;
                 t[q].c = lds_f4(lds, off);
                 t[q].n = lds_f4(lds, C::PLANE_BYTES + off);
@@ -509,33 +510,31 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         auto taps = [&](auto zero_aware) {
             constexpr bool ZA = decltype(zero_aware)::value;
             // per-output order stays dx outer / dy inner: A sees rows 0..4 as dy=-2..2, B rows 1..5
-            auto weigh_grp = [&](const int grp, const Tap (&t)[2]) {
-                const int dxi = grp / 3, tr0 = (grp % 3) * 2;
+            auto weigh_grp = [&](const int grp, const Tap (&t)[GR]) {
+                const int dxi = grp / (6 / GR), tr0 = (grp % (6 / GR)) * GR;
                 const int dx = dxi - 2;
                 const int adx = dx < 0 ? -dx : dx;
                 const bool colv = !EDGE || (x + dx * S >= 0 && x + dx * S < g.W);
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < GR; ++q) {
                     const int tr = tr0 + q;
-                    const float ecol = (!EDGE || (colv && rowv[tr])) ? kLogB3[adx] : kNegInf;
+                    const bool valid = !EDGE || (colv && rowv[tr]);
                     const int dyA = tr - 2, dyB = tr - 3;
                     const int adyA = dyA < 0 ? -dyA : dyA, adyB = dyB < 0 ? -dyB : dyB;
-                    if (tr == 0) {
-                        tap_single<ZA>(sA, kA, xA, t[q], ecol + kLogB3[adyA], adx, adyA, a.sigma_n);
-                    } else if (tr == 5) {
-                        tap_single<ZA>(sB, kB, xB, t[q], ecol + kLogB3[adyB], adx, adyB, a.sigma_n);
-                    } else {
-                        const f2 e0 = { ecol + kLogB3[adyA], ecol + kLogB3[adyB] };
-                        tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0, adx, adyA, adyB, a.sigma_n);
-                    }
+                    // log2 k of the tap, or -inf for a tap outside the frame (w becomes exactly 0)
+                    const float e0A = valid ? kLogB3[adx] + kLogB3[adyA] : kNegInf;
+                    const float e0B = valid ? kLogB3[adx] + kLogB3[adyB] : kNegInf;
+                    if (tr == 0)      tap_single<ZA>(sA, kA, xA, t[q], e0A, adx, adyA, a.sigma_n);
+                    else if (tr == 5) tap_single<ZA>(sB, kB, xB, t[q], e0B, adx, adyB, a.sigma_n);
+                    else              tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0A, e0B, adx, adyA, adyB, a.sigma_n);
                 }
             };
-            Tap t0[2], t1[2];
+            Tap t0[GR], t1[GR];
             load_grp(0, t0);
 #pragma unroll
-            for (int grp = 0; grp < 15; ++grp) {
-                if (grp & 1) { if (grp < 14) load_grp(grp + 1, t0); weigh_grp(grp, t1); }
-                else         { if (grp < 14) load_grp(grp + 1, t1); weigh_grp(grp, t0); }
+            for (int grp = 0; grp < NG; ++grp) {
+                if (grp & 1) { if (grp < NG - 1) load_grp(grp + 1, t0); weigh_grp(grp, t1); }
+                else         { if (grp < NG - 1) load_grp(grp + 1, t1); weigh_grp(grp, t0); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -621,11 +620,24 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
     a.nstrips = (a.g.W + C::CW - 1) / C::CW;
     // one resident wave of workgroups: WG_PER_CU per CU (LDS-limited) x 256 CUs
     const int per_band = a.nstrips * S;
-    int nb = (C::WG_PER_CU * kCus) / per_band;
-    if (nb < 1) nb = 1;
-    int bh = (rows + nb - 1) / nb;
     const int unit = S * C::ADV;                        // whole steps per lattice
-    bh = ((bh + unit - 1) / unit) * unit;
+    // Number of bands: every workgroup does the same work, so the launch runs in
+    // ceil(workgroups / resident slots) rounds; pick the band count that fills the rounds best,
+    // discounted by the 4 halo rows each workgroup stages on top of its own lattice rows.
+    const int slots = C::WG_PER_CU * kCus;
+    int bh = ((rows + unit - 1) / unit) * unit;
+    double best = -1.0;
+    for (int nb = 1; nb <= 64; ++nb) {
+        int h = (rows + nb - 1) / nb;
+        h = ((h + unit - 1) / unit) * unit;
+        const int bands = (rows + h - 1) / h;
+        const int wgs = bands * per_band;
+        const int rounds = (wgs + slots - 1) / slots;
+        const double lattice_rows = (double)h / S;
+        const double eff = (double)wgs / ((double)rounds * slots) * lattice_rows / (lattice_rows + 4.0);
+        if (eff > best + 1e-9) { best = eff; bh = h; }
+        if (h == unit) break;
+    }
     a.band_h = bh;
     const int nbands = (a.row1 - 1) / bh - a.row0 / bh + 1;     // bands are globally aligned
     a.nblocks = nbands * per_band;
