@@ -309,7 +309,9 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     using C = StreamCfg<S, NP>;
     const Geom g = a.g;
     const int col = tid % C::CW;                      // column inside the strip
-    const int pr = tid / C::CW;                       // row pair of this thread (wave-uniform)
+    // row pair of this thread: the same for a whole wave (CW is a multiple of 64), said so explicitly
+    // so that every row number and row address derived from it stays in SGPRs
+    const int pr = __builtin_amdgcn_readfirstlane(tid / C::CW);
     const int x = x0 + col;
     const bool xin = !EDGE || x < g.W;
     const float* in_f = reinterpret_cast<const float*>(a.in);
