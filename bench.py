@@ -97,25 +97,28 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps):
 
 
 def cpu_baseline():
-    """Scalar oracle, all host threads, on a bounded sample: 2 frames of full SVGF at 1920x1080
-    synthetic (the 2nd, with history, is timed).  A reported baseline, not a target."""
+    """Scalar oracle, all host threads, on a bounded sample: frames 1..3 of a 4-frame 1920x1080
+    synthetic sequence of full SVGF (frame 0 only builds history).  A reported baseline, not a
+    target; the reference has no CPU path to time."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as orc
-    w, h = 1920, 1080
+    w, h, frames = 1920, 1080, 4
     cores = orc.hardware_threads()
     p = orc.default_params()
     hc = hm = pn = None
-    dt = None
-    for f in range(2):
+    dt = 0.0
+    for f in range(frames):
         c, nd, m = orc.synth_gbuffer(w, h, f)
         fr = orc.Frame(w, h, c, nd, m, hc, hm, pn, debug=False)
         t0 = time.perf_counter()
         orc.frame(fr, p, threads=cores)
-        dt = time.perf_counter() - t0
+        if f > 0:
+            dt += time.perf_counter() - t0
         hc, hm, pn = fr.hist_color_out, fr.t_moments, fr.nd
-    return {"value": round(w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
-            "sample": "1 frame (2nd of 2) of full SVGF at 1920x1080 synthetic, scalar C oracle (gcc -O2, "
-                      "-ffp-contract=off), static row strips on all host threads", "seconds": round(dt, 3)}
+    return {"value": round((frames - 1) * w * h / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{frames - 1} frames (after 1 history-building frame) of full SVGF at 1920x1080 synthetic, scalar C "
+                      "oracle (gcc -O2 -ffp-contract=off), static row strips on all host threads",
+            "seconds": round(dt, 3), "core_seconds": round(dt * cores, 1)}
 
 
 def main():
@@ -131,11 +134,19 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # RMD_DIST_BACKEND=gloo rehearses the N>1 path with several ranks sharing one GPU (RCCL refuses
+    # two ranks on one device); the driver's runs use the default: one rank per GPU over RCCL/xGMI.
+    backend = os.environ.get("RMD_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     rmd.check(rmd.lib.rmd_set_device(local))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if world == 1:
         width, height = 3840, 2160
@@ -176,7 +187,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -104,13 +104,34 @@ def halo_ops(plan: StripPlan, hist_color, hist_moments, group=None):
 
 
 def exchange_history_halo(plan: StripPlan, hist_color, hist_moments, group=None):
-    """Blocking form: post the batched isend/irecv group and wait for it."""
-    ops = halo_ops(plan, hist_color, hist_moments, group)
-    if not ops:
+    """Blocking form: post the batched isend/irecv group and wait for it.
+
+    With RCCL ("nccl") the device rows travel directly over xGMI.  With gloo and device planes (the
+    one-GPU rehearsal of the multi-rank path) the rows are staged through host memory.
+    """
+    steps = halo_plan(plan)
+    if not steps:
         return 0
+    planes = {"color": hist_color, "moments": hist_moments}
+    staged = hist_color.is_cuda and dist.get_backend(group) == "gloo"
+    if not staged:
+        for req in dist.batch_isend_irecv(halo_ops(plan, hist_color, hist_moments, group)):
+            req.wait()
+        return len(steps)
+    ops, landing = [], []
+    for kind, name, lo, hi, peer in steps:
+        rows = _rows(planes[name], plan, lo, hi)
+        if kind == "send":
+            ops.append(dist.P2POp(dist.isend, rows.cpu(), peer, group))
+        else:
+            host = torch.empty(rows.shape, dtype=rows.dtype)
+            landing.append((rows, host))
+            ops.append(dist.P2POp(dist.irecv, host, peer, group))
     for req in dist.batch_isend_irecv(ops):
         req.wait()
-    return len(ops)
+    for rows, host in landing:
+        rows.copy_(host)
+    return len(steps)
 
 
 def halo_bytes(plan: StripPlan, width):
