@@ -93,10 +93,13 @@ int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int r
         return fail(RMD_E_NULL, "rmd_svgf_frame: ping planes are NULL");
     const int H = f->height;
 
+    // T also fills v_color, so V only rewrites short-history pixels (when statistics are wanted V
+    // runs unfused: it then has to visit every pixel anyway)
+    const bool fuse = f->stats == nullptr;
     const int t0 = clampi(row0 - r.t, 0, H), t1 = clampi(row1 + r.t, 0, H);
-    if (int e = rmd_svgf_temporal(f, p, t0, t1, stream)) return e;
+    if (int e = launch_temporal(f, p, t0, t1, stream, fuse)) return e;
     const int v0 = clampi(row0 - r.v, 0, H), v1 = clampi(row1 + r.v, 0, H);
-    if (int e = rmd_svgf_variance(f, p, v0, v1, stream)) return e;
+    if (int e = launch_variance(f, p, v0, v1, stream, fuse)) return e;
 
     const float* in = f->v_color;
     int pp = 0;

@@ -19,6 +19,7 @@ struct TemporalArgs {
     const float4* color; const float4* nd; const float2* motion;
     const float4* hist_color; const float4* hist_moments; const float4* prev_nd;
     float4* t_color; float4* t_moments; int4* t_debug;
+    float4* v_color;          // optional second copy of t_color (fused frame: V then only rewrites short-history pixels)
     int row0, row1;
     float alpha_color, alpha_moments, k_z, k_n;
     int h_max, max_motion_rows;
@@ -57,25 +58,38 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     float wsum = 0.0f, pcx = 0.0f, pcy = 0.0f, pcz = 0.0f, pm1 = 0.0f, pm2 = 0.0f;
     float best_w = -1.0f;
     int best_h = 0;
+    if (a.prev_nd) {                               // NULL = no history yet (first frame / after a reset)
+        // All twelve history gathers are issued up front, at tap coordinates clamped into the rows
+        // the planes hold, and validity is decided afterwards: a dependent load-test-load chain per
+        // tap keeps too few bytes in flight for an HBM-bound pass.  Same arithmetic, same order.
+        const int ylo = max(max(g.buf_row0, 0), y - a.max_motion_rows);
+        const int yhi = min(min(g.buf_row0 + g.buf_rows, g.H) - 1, y + a.max_motion_rows);
+        size_t ti[4];
+        bool inb[4];
+        float4 pn[4], hc[4], hm[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!a.prev_nd) break;                     // no history yet (first frame / after a reset)
-        const int tx = q0x + (k & 1), ty = q0y + (k >> 1);
-        if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
-        if (abs(ty - y) > a.max_motion_rows) continue;
-        const size_t ti = pix_index(g, tx, ty);
-        const float4 pn = a.prev_nd[ti];
-        if (!(fabsf(pn.w - nd.w) <= zthr)) continue;
-        const bool ok_n = p_zero ? is_zero3(pn) : ((pn.x * nd.x + pn.y * nd.y + pn.z * nd.z) >= a.k_n);
-        if (!ok_n) continue;
-        mask |= 1 << k;
-        const float4 hc = a.hist_color[ti];
-        const float4 hm = a.hist_moments[ti];
-        const float w = wk[k];
-        wsum += w;
-        pcx += w * hc.x; pcy += w * hc.y; pcz += w * hc.z;
-        pm1 += w * hm.x; pm2 += w * hm.y;
-        if (w > best_w) { best_w = w; best_h = (int)hm.z; }
+        for (int k = 0; k < 4; ++k) {
+            const int tx = q0x + (k & 1), ty = q0y + (k >> 1);
+            inb[k] = tx >= 0 && tx < g.W && ty >= 0 && ty < g.H && abs(ty - y) <= a.max_motion_rows;
+            ti[k] = pix_index(g, min(max(tx, 0), g.W - 1), min(max(ty, ylo), yhi));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pn[k] = a.prev_nd[ti[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { hc[k] = a.hist_color[ti[k]]; hm[k] = a.hist_moments[ti[k]]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!inb[k]) continue;
+            if (!(fabsf(pn[k].w - nd.w) <= zthr)) continue;
+            const bool ok_n = p_zero ? is_zero3(pn[k]) : ((pn[k].x * nd.x + pn[k].y * nd.y + pn[k].z * nd.z) >= a.k_n);
+            if (!ok_n) continue;
+            mask |= 1 << k;
+            const float w = wk[k];
+            wsum += w;
+            pcx += w * hc[k].x; pcy += w * hc[k].y; pcz += w * hc[k].z;
+            pm1 += w * hm[k].x; pm2 += w * hm[k].y;
+            if (w > best_w) { best_w = w; best_h = (int)hm[k].z; }
+        }
     }
 
     // A.T.3
@@ -98,7 +112,9 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     float var = m2 - m1 * m1;
     if (!(var > 0.0f)) var = 0.0f;
 
-    a.t_color[i] = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
+    const float4 tc = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
+    a.t_color[i] = tc;
+    if (a.v_color) a.v_color[i] = tc;
     a.t_moments[i] = make_float4(m1, m2, (float)h, 0.0f);
     if (a.t_debug) a.t_debug[i] = make_int4(q0x, q0y, mask, h);
 }
@@ -107,7 +123,7 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
 
 using namespace rmd;
 
-extern "C" int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool also_v_color)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_temporal: params is NULL");
@@ -134,6 +150,12 @@ extern "C" int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_pa
     a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float4*)f->hist_moments;
     a.prev_nd = (const float4*)f->prev_nd;
     a.t_color = (float4*)f->t_color; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
+    a.v_color = nullptr;
+    if (also_v_color) {
+        if (!f->v_color || !aligned_to(f->v_color, 16) || f->v_color == f->t_color)
+            return fail(RMD_E_NULL, "rmd_svgf_temporal: fused v_color plane is NULL, misaligned or aliases t_color");
+        a.v_color = (float4*)f->v_color;
+    }
     a.row0 = row0; a.row1 = row1;
     a.alpha_color = p->alpha_color; a.alpha_moments = p->alpha_moments; a.k_z = p->k_z; a.k_n = p->k_n;
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
@@ -141,4 +163,9 @@ extern "C" int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_pa
     hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
     RMD_LAUNCH_CHECK("svgf_temporal_kernel");
     return RMD_OK;
+}
+
+extern "C" int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+{
+    return rmd::launch_temporal(f, p, row0, row1, stream, /*also_v_color=*/false);
 }

@@ -19,6 +19,7 @@ struct VarianceArgs {
     float4* v_color; float* stats;
     int row0, row1;
     int h_threshold, radius;
+    int prefilled;            // v_color already holds t_color (fused frame): long-history pixels are left alone
     float sigma_n, sigma_z;
 };
 
@@ -32,10 +33,12 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
     float s_var = 0.0f, s_spatial = 0.0f, s_h = 0.0f, s_n = 0.0f;
     if (active) {
         const size_t i = pix_index(g, x, y);
-        const float4 c = a.t_color[i];
         const int h = (int)a.t_moments[i].z;
+        const bool spatial = h < a.h_threshold;
+        if (!spatial && a.prefilled) return;       // (prefilled launches collect no statistics)
+        const float4 c = a.t_color[i];
         float4 o = c;
-        if (h < a.h_threshold) {
+        if (spatial) {
             const float4 nd = a.nd[i];
             const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
             const float gz = fabsf(a.nd[pix_index(g, x1, y)].w - nd.w) + fabsf(a.nd[pix_index(g, x, y1)].w - nd.w);
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
 
 using namespace rmd;
 
-extern "C" int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool prefilled)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_variance: params is NULL");
@@ -124,9 +127,15 @@ extern "C" int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_pa
     a.v_color = (float4*)f->v_color; a.stats = f->stats;
     a.row0 = row0; a.row1 = row1;
     a.h_threshold = p->var_h_threshold; a.radius = p->var_radius;
+    a.prefilled = (prefilled && !f->stats) ? 1 : 0;
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z;
     dim3 grid((f->width + 63) / 64, (row1 - row0 + 3) / 4);
     hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, as_stream(stream), a);
     RMD_LAUNCH_CHECK("svgf_variance_kernel");
     return RMD_OK;
+}
+
+extern "C" int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+{
+    return rmd::launch_variance(f, p, row0, row1, stream, /*prefilled=*/false);
 }
