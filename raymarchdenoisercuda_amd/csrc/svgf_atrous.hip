@@ -323,6 +323,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     float4 pc[2], pn[2], pe[C::NT];
     float pvu[2], pvd[2], pzd[2], pvh = 0.0f;
     float zd_cur[2] = { 0.0f, 0.0f };
+    float4 outA, outB;                                // results of the current step
 
     // Global addresses are formed as (wave-uniform row base) + (lane index): the uniform part
     // stays in SGPRs (global_load ... saddr), only the lane offset lives in a VGPR.
@@ -520,7 +521,10 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
 #pragma unroll
                 for (int q = 0; q < GR; ++q) {
                     const int tr = tr0 + q;
-                    const bool valid = !EDGE || (colv && rowv[tr]);
+                    // Taps outside the frame are staged as zeros.  A zero tap normal gives
+                    // log2(0) = -inf, i.e. weight exactly 0, whenever the centre normal is non-zero,
+                    // so only the zero-aware path needs an explicit mask.
+                    const bool valid = !EDGE || !ZA || (colv && rowv[tr]);
                     const int dyA = tr - 2, dyB = tr - 3;
                     const int adyA = dyA < 0 ? -dyA : dyA, adyB = dyB < 0 ? -dyB : dyB;
                     // log2 k of the tap, or -inf for a tap outside the frame (w becomes exactly 0)
@@ -545,13 +549,17 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         // Per-pixel sums = (row only this pixel taps: dy=-2 for role A, dy=+2 for role B) + (the four
         // rows shared with its partner), each summed dx outer / dy inner.  The direct kernel groups
         // its 25 taps the same way, so the two variants stay bit-identical.
+        outA = finish(sA.sw + sAB.sw.x, sA.sl + sAB.sl.x, sA.sr + sAB.sr.x, sA.sg + sAB.sg.x, sA.sv + sAB.sv.x, cA.c);
+        outB = finish(sB.sw + sAB.sw.y, sB.sl + sAB.sl.y, sB.sr + sAB.sr.y, sB.sg + sAB.sg.y, sB.sv + sAB.sv.y, cB.c);
+    };
+    // The two output pixels of step j are written AFTER the ring refill of the step: the refill has to
+    // wait for the prefetch loads (vmcnt), and stores issued before it would be waited for as well.
+    auto write_out = [&](const int j) {
+        const int jw = j + 2 * pr;
+        const int yA = ybase + jw * S;
         if (xin) {
-            if (jw >= jlo && jw < jhi)
-                (a.out + row_base(yA, x0))[col] = finish(sA.sw + sAB.sw.x, sA.sl + sAB.sl.x, sA.sr + sAB.sr.x, sA.sg + sAB.sg.x,
-                                                         sA.sv + sAB.sv.x, cA.c);
-            if (jw + 1 >= jlo && jw + 1 < jhi)
-                (a.out + row_base(yB, x0))[col] = finish(sB.sw + sAB.sw.y, sB.sl + sAB.sl.y, sB.sr + sAB.sr.y,
-                                                         sB.sg + sAB.sg.y, sB.sv + sAB.sv.y, cB.c);
+            if (jw >= jlo && jw < jhi) (a.out + row_base(yA, x0))[col] = outA;
+            if (jw + 1 >= jlo && jw + 1 < jhi) (a.out + row_base(yA + S, x0))[col] = outB;
         }
     };
 
@@ -570,9 +578,10 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         const bool more = j + C::ADV < jhi;
         if (more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute
         compute(j);
-        if (!more) break;
+        if (!more) { write_out(j); break; }
         __syncthreads();                                     // every wave is done reading the ADV oldest rows
         store_rows(j - 2 + C::NR); store_aux();
+        write_out(j);
         __syncthreads();
     }
 }

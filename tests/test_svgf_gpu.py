@@ -104,10 +104,11 @@ def test_variance_parity(rmd, orc, cuda, width, height):
         assert abs(s[0] - fr.v_color[..., 3].sum()) <= 1e-3 * (1 + fr.v_color[..., 3].sum())
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("width,height", SIZES)
 def test_atrous_each_iteration(rmd, orc, cuda, width, height, variant):
-    """Every iteration in isolation (oracle-fed input), both kernel variants."""
+    """Every iteration in isolation (oracle-fed input): direct kernel (1), LDS stream kernel with
+    one row pair per workgroup (2) and with two (3, the default)."""
     p = orc.default_params()
     p.atrous_variant = variant
     fr = oracle_sequence(orc, width, height, 2, p)[1]
@@ -133,14 +134,15 @@ def test_stream_kernel_equals_direct_kernel_bitwise(rmd, cuda, width, height):
     src = c
     for it in range(5):
         outs = []
-        for variant in (1, 2):
+        for variant in (1, 2, 3):
             p.atrous_variant = variant
             o = torch.full_like(c, float("nan"))
             rmd.svgf.atrous(d, p, it, src, o, 0, height)
             outs.append(o)
         torch.cuda.synchronize()
-        assert torch.equal(outs[0], outs[1]), f"iteration {it}: {(outs[0] != outs[1]).sum().item()} values differ"
-        src = outs[1]
+        for k in (1, 2):
+            assert torch.equal(outs[0], outs[k]), f"iteration {it} variant {k + 1}: {(outs[0] != outs[k]).sum().item()} values differ"
+        src = outs[2]
 
 
 def test_atrous_zero_normals_cornell(rmd, orc, cuda):
@@ -152,7 +154,7 @@ def test_atrous_zero_normals_cornell(rmd, orc, cuda):
     fr = orc.Frame(w, h, color, nd, motion)
     p = orc.default_params()
     d, t, _ = gpu_frame_desc(rmd, fr)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         p.atrous_variant = variant
         src = color
         for it in range(5):
@@ -340,3 +342,50 @@ def test_4k_properties(rmd, cuda):
             assert torch.equal(chk[r0:r1], o[r0:r1]), f"iteration {it} rows {r0}:{r1}"
         src = o
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("width,height", [(1, 1), (2, 3), (5, 70), (130, 2), (33, 33), (257, 9)])
+def test_degenerate_frame_sizes(rmd, orc, cuda, width, height):
+    """Ragged / tiny frames: every tap row or column can fall outside the frame, strips are partial,
+    lattices have a single row.  Three frames of the full pipeline against the oracle."""
+    p = orc.default_params()
+    ref = oracle_sequence(orc, width, height, 3, p)
+    den = rmd.SvgfDenoiser(width, height, params=p, debug=True)
+    for f, fr in enumerate(ref):
+        out = den.denoise(dev(fr.color), dev(fr.nd), dev(fr.motion))
+        torch.cuda.synchronize()
+        assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}"
+        close(out, fr.out_color, TOL_FRAME, f"{width}x{height} frame {f}")
+    for variant in (1, 2, 3):                               # every a-trous variant on the last frame's input
+        p.atrous_variant = variant
+        d, t, _ = gpu_frame_desc(rmd, ref[-1])
+        src = ref[-1].v_color
+        for it in range(5):
+            want = np.zeros_like(src)
+            orc.atrous(ref[-1], p, it, src, want)
+            got = torch.full((height, width, 4), float("nan"), device="cuda")
+            rmd.svgf.atrous(d, p, it, dev(src), got, 0, height)
+            close(got, want, TOL_PASS, f"{width}x{height} variant {variant} iteration {it}")
+            src = want
+
+
+def test_invalid_arguments_are_rejected(rmd, cuda):
+    w, h = 64, 32
+    c, nd, m = rmd.svgf.synth_gbuffer(w, h, 0)
+    p = rmd.default_params()
+    d = rmd.svgf.frame_desc(w, h, nd=nd)
+    out = torch.empty_like(c)
+    with pytest.raises(rmd.RmdError):
+        rmd.svgf.atrous(d, p, 0, c, c, 0, h)                   # in == out
+    with pytest.raises(rmd.RmdError):
+        rmd.svgf.atrous(d, p, 0, c, out, 5, 5)                 # empty row range
+    with pytest.raises(rmd.RmdError):
+        rmd.svgf.atrous(d, p, 13, c, out, 0, h)                # iteration out of range
+    p.sigma_n = 0.0
+    with pytest.raises(rmd.RmdError):
+        rmd.svgf.atrous(d, p, 0, c, out, 0, h)
+    p = rmd.default_params()
+    strip = rmd.svgf.frame_desc(w, h, buf_row0=8, buf_rows=16, nd=nd[8:24].contiguous())
+    with pytest.raises(rmd.RmdError) as e:                     # taps of rows 8..24 at step 4 leave the buffer
+        rmd.svgf.atrous(strip, p, 2, c[8:24].contiguous(), out[8:24].contiguous(), 8, 24)
+    assert e.value.code == -5
