@@ -145,7 +145,12 @@ typedef struct rmd_svgf_frame_desc {
     float* stats;              /* optional 4 floats, ACCUMULATED by V with wavefront reductions:
                                   [0] sum of variance, [1] pixels on the spatial path,
                                   [2] sum of history length, [3] pixels processed              */
+    unsigned char* v_tile_flags; /* optional scratch used by rmd_svgf_frame: one byte per 64x4-pixel tile of
+                                  the GLOBAL frame, RMD_TILE_FLAGS_BYTES(width, height) bytes.  T marks
+                                  the tiles that contain short-history pixels, so V skips every other
+                                  tile without reading a byte of it.  NULL = V visits all pixels.     */
 } rmd_svgf_frame_desc;
+#define RMD_TILE_FLAGS_BYTES(width, height) ((size_t)(((width) + 63) / 64) * (size_t)(((height) + 3) / 4))
 
 /* Pass launchers.  [row0,row1) are GLOBAL output rows. */
 int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);

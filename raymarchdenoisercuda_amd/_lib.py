@@ -64,7 +64,7 @@ class SvgfFrameDesc(C.Structure):
                 ("hist_color", C.c_void_p), ("hist_moments", C.c_void_p), ("prev_nd", C.c_void_p),
                 ("t_color", C.c_void_p), ("t_moments", C.c_void_p), ("t_debug", C.c_void_p),
                 ("v_color", C.c_void_p), ("hist_color_out", C.c_void_p), ("ping", C.c_void_p * 2),
-                ("out_color", C.c_void_p), ("stats", C.c_void_p)]
+                ("out_color", C.c_void_p), ("stats", C.c_void_p), ("v_tile_flags", C.c_void_p)]
 
 
 class SynthDesc(C.Structure):

@@ -49,8 +49,10 @@ int check_rows_in_buffer(const rmd_svgf_frame_desc* f, int lo, int hi, const cha
 // Pass launchers behind rmd_svgf_temporal / rmd_svgf_variance.  rmd_svgf_frame fuses the V pass's
 // pass-through copy into T: T writes its colour to t_color AND v_color, V then only rewrites the
 // pixels on the spatial path (saves 32 B/px of the 64 B/px V would move).
-int launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool also_v_color);
-int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool prefilled);
+// With f->v_tile_flags set, T also marks the 64x4 tiles (global tiling) that hold short-history
+// pixels and V returns at once from every unmarked tile.
+int launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
+int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
 
 }  // namespace rmd
 

@@ -51,6 +51,7 @@ struct rmd_svgf_context {
     float* t_color;
     float* v_color;
     float* ping[2];
+    unsigned char* tile_flags;
     int cur;            // index of the history set the next frame reads
     bool has_history;
 };
@@ -143,6 +144,18 @@ int rmd_svgf_context_create(int width, int height, int buf_row0, int buf_rows, r
             return hip_fail(e, "rmd_svgf_context_create: hipMalloc");
         }
     }
+    c->tile_flags = nullptr;
+    {
+        const size_t fb = RMD_TILE_FLAGS_BYTES(width, height);
+        hipError_t e = hipMalloc((void**)&c->tile_flags, fb);
+        if (e == hipSuccess) e = hipMemset(c->tile_flags, 0, fb);
+        if (e != hipSuccess) {
+            for (float** z : planes) if (*z) (void)hipFree(*z);
+            if (c->tile_flags) (void)hipFree(c->tile_flags);
+            delete c;
+            return hip_fail(e, "rmd_svgf_context_create: hipMalloc(tile flags)");
+        }
+    }
     *out = c;
     return RMD_OK;
 }
@@ -150,6 +163,7 @@ int rmd_svgf_context_create(int width, int height, int buf_row0, int buf_rows, r
 void rmd_svgf_context_destroy(rmd_svgf_context* c)
 {
     if (!c) return;
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
     float* planes[] = { c->hist_color[0], c->hist_color[1], c->hist_moments[0], c->hist_moments[1],
                         c->t_color, c->v_color, c->ping[0], c->ping[1] };
     for (float* q : planes) if (q) (void)hipFree(q);
@@ -178,6 +192,7 @@ int rmd_svgf_context_describe(rmd_svgf_context* c, rmd_svgf_frame_desc* f)
     f->v_color = c->v_color;
     f->hist_color_out = c->hist_color[c->cur ^ 1];
     f->ping[0] = c->ping[0]; f->ping[1] = c->ping[1];
+    f->v_tile_flags = c->tile_flags;
     return RMD_OK;
 }
 

@@ -20,6 +20,8 @@ struct TemporalArgs {
     const float4* hist_color; const float4* hist_moments; const float4* prev_nd;
     float4* t_color; float4* t_moments; int4* t_debug;
     float4* v_color;          // optional second copy of t_color (fused frame: V then only rewrites short-history pixels)
+    unsigned char* tile_flags; // optional: 1 per 64x4 tile (global tiling) holding a pixel with h < var_h_threshold
+    int tiles_x, var_h_threshold;
     int row0, row1;
     float alpha_color, alpha_moments, k_z, k_n;
     int h_max, max_motion_rows;
@@ -30,9 +32,12 @@ __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (
 __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
 {
     const Geom g = a.g;
+    // workgroup = one 64x4 tile of the GLOBAL tiling (rows 4k..4k+3), so T and V agree on tiles
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = a.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= g.W || y >= a.row1) return;
+    const int tile_y = a.row0 / 4 + blockIdx.y;
+    const int y = tile_y * 4 + (threadIdx.x >> 6);
+    bool short_history = false;
+    if (x < g.W && y >= a.row0 && y < a.row1) {
     const size_t i = pix_index(g, x, y);
 
     const float4 c = a.color[i];
@@ -117,13 +122,19 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     if (a.v_color) a.v_color[i] = tc;
     a.t_moments[i] = make_float4(m1, m2, (float)h, 0.0f);
     if (a.t_debug) a.t_debug[i] = make_int4(q0x, q0y, mask, h);
+    short_history = h < a.var_h_threshold;
+    }
+    if (a.tile_flags) {
+        const int any = __syncthreads_or(short_history ? 1 : 0);
+        if (threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + blockIdx.x] = (unsigned char)(any != 0);
+    }
 }
 
 }  // namespace rmd
 
 using namespace rmd;
 
-int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool also_v_color)
+int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_temporal: params is NULL");
@@ -151,7 +162,9 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.prev_nd = (const float4*)f->prev_nd;
     a.t_color = (float4*)f->t_color; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
     a.v_color = nullptr;
-    if (also_v_color) {
+    a.tile_flags = nullptr; a.tiles_x = (f->width + 63) / 64; a.var_h_threshold = p->var_h_threshold;
+    if (fused) {
+        a.tile_flags = f->v_tile_flags;
         if (!f->v_color || !aligned_to(f->v_color, 16) || f->v_color == f->t_color)
             return fail(RMD_E_NULL, "rmd_svgf_temporal: fused v_color plane is NULL, misaligned or aliases t_color");
         a.v_color = (float4*)f->v_color;
@@ -159,7 +172,7 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.row0 = row0; a.row1 = row1;
     a.alpha_color = p->alpha_color; a.alpha_moments = p->alpha_moments; a.k_z = p->k_z; a.k_n = p->k_n;
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
-    dim3 grid((f->width + 63) / 64, (row1 - row0 + 3) / 4);
+    dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
     hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
     RMD_LAUNCH_CHECK("svgf_temporal_kernel");
     return RMD_OK;
@@ -167,5 +180,5 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
 
 extern "C" int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
 {
-    return rmd::launch_temporal(f, p, row0, row1, stream, /*also_v_color=*/false);
+    return rmd::launch_temporal(f, p, row0, row1, stream, /*fused=*/false);
 }

@@ -20,15 +20,20 @@ struct VarianceArgs {
     int row0, row1;
     int h_threshold, radius;
     int prefilled;            // v_color already holds t_color (fused frame): long-history pixels are left alone
+    const unsigned char* tile_flags;   // fused frame: tiles T marked as holding short-history pixels
+    int tiles_x;
     float sigma_n, sigma_z;
 };
 
 __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
 {
     const Geom g = a.g;
+    // workgroup = one 64x4 tile of the GLOBAL tiling, the same tiles T flags
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = a.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    const bool active = x < g.W && y < a.row1;
+    const int tile_y = a.row0 / 4 + blockIdx.y;
+    const int y = tile_y * 4 + (threadIdx.x >> 6);
+    if (a.tile_flags && a.tile_flags[(size_t)tile_y * a.tiles_x + blockIdx.x] == 0) return;   // whole tile: long history
+    const bool active = x < g.W && y >= a.row0 && y < a.row1;
 
     float s_var = 0.0f, s_spatial = 0.0f, s_h = 0.0f, s_n = 0.0f;
     if (active) {
@@ -107,7 +112,7 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
 
 using namespace rmd;
 
-int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool prefilled)
+int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_variance: params is NULL");
@@ -127,9 +132,11 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.v_color = (float4*)f->v_color; a.stats = f->stats;
     a.row0 = row0; a.row1 = row1;
     a.h_threshold = p->var_h_threshold; a.radius = p->var_radius;
-    a.prefilled = (prefilled && !f->stats) ? 1 : 0;
+    a.prefilled = (fused && !f->stats) ? 1 : 0;
+    a.tile_flags = a.prefilled ? f->v_tile_flags : nullptr;
+    a.tiles_x = (f->width + 63) / 64;
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z;
-    dim3 grid((f->width + 63) / 64, (row1 - row0 + 3) / 4);
+    dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
     hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, as_stream(stream), a);
     RMD_LAUNCH_CHECK("svgf_variance_kernel");
     return RMD_OK;
@@ -137,5 +144,5 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
 
 extern "C" int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
 {
-    return rmd::launch_variance(f, p, row0, row1, stream, /*prefilled=*/false);
+    return rmd::launch_variance(f, p, row0, row1, stream, /*fused=*/false);
 }

@@ -40,7 +40,13 @@ def _ptr(t, name, rows, width, channels, dtype=torch.float32):
     return t.data_ptr()
 
 
-def frame_desc(width, height, buf_row0=0, buf_rows=None, ping=(None, None), stats=None, **planes) -> SvgfFrameDesc:
+def tile_flags_bytes(width, height):
+    """RMD_TILE_FLAGS_BYTES of include/rmd_api.h."""
+    return ((width + 63) // 64) * ((height + 3) // 4)
+
+
+def frame_desc(width, height, buf_row0=0, buf_rows=None, ping=(None, None), stats=None, tile_flags=None,
+               **planes) -> SvgfFrameDesc:
     """Descriptor over torch planes of shape [buf_rows, width, C] (caller keeps them alive)."""
     buf_rows = height if buf_rows is None else buf_rows
     d = SvgfFrameDesc()
@@ -56,6 +62,10 @@ def frame_desc(width, height, buf_row0=0, buf_rows=None, ping=(None, None), stat
         if not (stats.is_cuda and stats.dtype == torch.float32 and stats.numel() >= 4):
             raise ValueError("stats: expected a CUDA float32 tensor with >= 4 elements")
         d.stats = stats.data_ptr()
+    if tile_flags is not None:
+        if not (tile_flags.is_cuda and tile_flags.dtype == torch.uint8 and tile_flags.numel() >= tile_flags_bytes(width, height)):
+            raise ValueError("tile_flags: expected a CUDA uint8 tensor of tile_flags_bytes(width, height) elements")
+        d.v_tile_flags = tile_flags.data_ptr()
     return d
 
 
@@ -135,6 +145,7 @@ class SvgfDenoiser:
         self.t_debug = torch.zeros((self.buf_rows, width, 4), dtype=torch.int32, device=device) if debug else None
         # frame statistics accumulated by the V pass (diagnostics; costs atomics, so opt-in)
         self.stats = torch.zeros(4, dtype=torch.float32, device=device) if collect_stats else None
+        self.tile_flags = torch.zeros(tile_flags_bytes(width, height), dtype=torch.uint8, device=device)
         self.cur = 0
         self.has_history = False
         self.prev_nd = None
@@ -157,7 +168,7 @@ class SvgfDenoiser:
             prev_nd=self.prev_nd if use_hist else None,
             t_color=self.t_color, t_moments=self.hist_moments[self.cur ^ 1], t_debug=self.t_debug,
             v_color=self.v_color, hist_color_out=self.hist_color[self.cur ^ 1],
-            ping=(self.ping[0], self.ping[1]), out_color=out, stats=self.stats)
+            ping=(self.ping[0], self.ping[1]), out_color=out, stats=self.stats, tile_flags=self.tile_flags)
 
     def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None):
         """One frame.  `nd` is borrowed until the next call (it becomes prev_nd)."""
