@@ -158,7 +158,10 @@ def main():
     p = rmd.default_params()
     p.max_motion_rows = 8            # the synthetic pan moves <= 1.5 rows per frame
     p.atrous_variant = int(os.environ.get("RMD_ATROUS_VARIANT", "0"))   # 0 = library default (experiments only)
-    sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world)
+    # consecutive frames are software-pipelined over two HIP streams (T+V of frame k+1 under the
+    # a-trous iterations of frame k); RMD_PIPELINE=0 runs the 7 launches of a frame back to back
+    pipelined = os.environ.get("RMD_PIPELINE", "1") != "0"
+    sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world, pipelined=pipelined)
     plan = sd.plan
     rows_out = plan.row1 - plan.row0
 
@@ -199,7 +202,8 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "frame": [width, height], "rows_per_gpu": rows_out,
-                   "parallelism": f"row-strip x{world}", "passes": "T + V + 5 x A (7 launches/frame)"},
+                   "parallelism": f"row-strip x{world}", "passes": "T + V + 5 x A (7 launches/frame)",
+                   "frame_pipelining": "T+V of frame k+1 overlap A1..A4 of frame k (2 streams)" if pipelined else "none"},
         "effective_GBps_full_svgf": round(FULL_BYTES_PER_PX * total_px / dt / 1e9, 1),
     }
     if world > 1:

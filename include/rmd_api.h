@@ -163,6 +163,14 @@ int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int 
  * the rows later passes tap (redundant rows instead of per-pass halo exchanges);
  * those rows are clamped to the global frame and must lie inside the buffer. */
 int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);
+/* The two halves of rmd_svgf_frame, for software pipelining across frames: T+V of frame k+1 only
+ * needs frame k's history, which is complete after frame k's `hist_iteration`, so it can run on a
+ * second stream underneath frame k's remaining a-trous iterations (T is HBM-bound, A is ALU-bound).
+ * rmd_svgf_frame_atrous records `history_ready_event` (a hipEvent_t, may be NULL) on `stream` right
+ * after the hist_iteration launch. */
+int rmd_svgf_frame_tv(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);
+int rmd_svgf_frame_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
+                          void* history_ready_event);
 /* Rows needed / produced above and below [row0,row1) by rmd_svgf_frame (for sizing buffers and
  * halo exchanges): reach[0] = current-frame input planes read, reach[1] = history planes read,
  * reach[2] = rows on which hist_color_out is (redundantly) produced, reach[3] = same for
@@ -220,6 +228,11 @@ int  rmd_host_free_pinned(void* ptr);
 int  rmd_stream_create(void** stream);
 int  rmd_stream_destroy(void* stream);
 int  rmd_stream_sync(void* stream);
+/* events order work across streams (frame pipelining): record on one stream, wait on another */
+int  rmd_event_create(void** event);
+int  rmd_event_destroy(void* event);
+int  rmd_event_record(void* event, void* stream);
+int  rmd_stream_wait_event(void* stream, void* event);
 int  rmd_device_sync(void);              /* reference cudaDeviceSynchronize(), src/test.cu:77,89 */
 int  rmd_device_count(int* count);
 int  rmd_set_device(int device);

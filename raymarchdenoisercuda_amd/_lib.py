@@ -83,6 +83,8 @@ SYMBOLS = {
     "rmd_svgf_variance": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
     "rmd_svgf_atrous": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "rmd_svgf_frame": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
+    "rmd_svgf_frame_tv": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
+    "rmd_svgf_frame_atrous": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P, _P]),
     "rmd_svgf_frame_reach": (C.c_int, [C.POINTER(SvgfParams), C.POINTER(C.c_int * 4)]),
     "rmd_svgf_context_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "rmd_svgf_context_destroy": (None, [_P]),
@@ -106,6 +108,10 @@ SYMBOLS = {
     "rmd_stream_create": (C.c_int, [C.POINTER(_P)]),
     "rmd_stream_destroy": (C.c_int, [_P]),
     "rmd_stream_sync": (C.c_int, [_P]),
+    "rmd_event_create": (C.c_int, [C.POINTER(_P)]),
+    "rmd_event_destroy": (C.c_int, [_P]),
+    "rmd_event_record": (C.c_int, [_P, _P]),
+    "rmd_stream_wait_event": (C.c_int, [_P, _P]),
     "rmd_device_sync": (C.c_int, []),
     "rmd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rmd_set_device": (C.c_int, [C.c_int]),

@@ -161,6 +161,36 @@ int rmd_stream_sync(void* stream)
     return RMD_OK;
 }
 
+int rmd_event_create(void** event)
+{
+    if (!event) return fail(RMD_E_NULL, "rmd_event_create: event is NULL");
+    hipEvent_t e;
+    RMD_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = e;
+    return RMD_OK;
+}
+
+int rmd_event_destroy(void* event)
+{
+    if (!event) return RMD_OK;
+    RMD_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return RMD_OK;
+}
+
+int rmd_event_record(void* event, void* stream)
+{
+    if (!event) return fail(RMD_E_NULL, "rmd_event_record: event is NULL");
+    RMD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(event), as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_stream_wait_event(void* stream, void* event)
+{
+    if (!event) return fail(RMD_E_NULL, "rmd_stream_wait_event: event is NULL");
+    RMD_HIP(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return RMD_OK;
+}
+
 int rmd_device_sync(void)
 {
     RMD_HIP(hipDeviceSynchronize());

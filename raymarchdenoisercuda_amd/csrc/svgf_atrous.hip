@@ -11,16 +11,19 @@
 //
 //  stream    the MI355X kernel.  At step S the image splits into S independent row lattices
 //            (rows y = r mod S): a tap at +-S, +-2S rows stays in the pixel's lattice.  A
-//            workgroup (4 wave64 = 256 threads) owns a 256-pixel-wide column strip of one
-//            lattice inside one band of rows and walks down it; a ring of 6 lattice rows
-//            (width 256 + 4S) lives in LDS, so every input row is fetched from L2/HBM once per
+//            workgroup (4 wave64 = 256 threads) owns a column strip of one lattice inside one
+//            band of rows and walks down it: NP groups of 256/NP threads, group p producing
+//            lattice rows j+2p, j+2p+1 of the step (default NP = 2: 128 columns x 4 rows per
+//            step; NP = 1: 256 columns x 2 rows).  A ring of 2NP+4 lattice rows (width
+//            256/NP + 4S) lives in LDS, so every input row is fetched from L2/HBM once per
 //            strip as 16-byte-per-lane coalesced segments and each of the 25 taps is a
 //            conflict-free ds_read_b128 with an immediate offset.  Each thread produces two
 //            vertically adjacent lattice pixels (A, B) per step: 30 tap fetches serve 50 weight
-//            evaluations, and the 40 evaluations whose tap both pixels share run as PACKED f32
-//            (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on the (A,B) register pair with the tap
-//            value broadcast through op_sel).  The next two lattice rows are prefetched into
-//            registers while the current pair is computed.  Workgroup ids are remapped so that
+//            evaluations, and the 40 evaluations whose tap both pixels share run their cosine
+//            and their five accumulations as PACKED f32 (v_pk_fma_f32 / v_pk_mul_f32 /
+//            v_pk_add_f32 on the (A,B) register pair, the tap value broadcast through op_sel).
+//            The next 2NP lattice rows are prefetched into registers while the current rows
+//            are computed.  Workgroup ids are remapped so that
 //            each XCD owns a contiguous run of (band, strip, lattice) work: neighbouring strips /
 //            lattices, which share halo columns and the +-1 variance rows, hit the same L2.
 //

@@ -81,10 +81,9 @@ int rmd_svgf_frame_reach(const rmd_svgf_params* p, int reach[4])
     return RMD_OK;
 }
 
-int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+static int check_frame_call(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, Reach& r)
 {
     if (int e = check_frame_geometry(f)) return e;
-    Reach r;
     if (int e = compute_reach(p, r)) return e;
     if (row0 < 0 || row1 > f->height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_svgf_frame: rows [%d,%d) invalid", row0, row1);
     if (!f->v_color || !f->out_color || !f->hist_color_out) return fail(RMD_E_NULL, "rmd_svgf_frame: v_color/out_color/hist_color_out is NULL");
@@ -92,16 +91,36 @@ int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int r
     const int pingpong_needed = n - 1 - (p->hist_iteration < n - 1 ? 1 : 0);
     if ((pingpong_needed >= 1 && !f->ping[0]) || (pingpong_needed >= 2 && !f->ping[1]))
         return fail(RMD_E_NULL, "rmd_svgf_frame: ping planes are NULL");
-    const int H = f->height;
+    return RMD_OK;
+}
 
+int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+{
+    if (int e = rmd_svgf_frame_tv(f, p, row0, row1, stream)) return e;
+    return rmd_svgf_frame_atrous(f, p, row0, row1, stream, nullptr);
+}
+
+int rmd_svgf_frame_tv(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
+{
+    Reach r;
+    if (int e = check_frame_call(f, p, row0, row1, r)) return e;
+    const int H = f->height;
     // T also fills v_color, so V only rewrites short-history pixels (when statistics are wanted V
     // runs unfused: it then has to visit every pixel anyway)
     const bool fuse = f->stats == nullptr;
     const int t0 = clampi(row0 - r.t, 0, H), t1 = clampi(row1 + r.t, 0, H);
     if (int e = launch_temporal(f, p, t0, t1, stream, fuse)) return e;
     const int v0 = clampi(row0 - r.v, 0, H), v1 = clampi(row1 + r.v, 0, H);
-    if (int e = launch_variance(f, p, v0, v1, stream, fuse)) return e;
+    return launch_variance(f, p, v0, v1, stream, fuse);
+}
 
+int rmd_svgf_frame_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
+                          void* history_ready_event)
+{
+    Reach r;
+    if (int e = check_frame_call(f, p, row0, row1, r)) return e;
+    const int H = f->height;
+    const int n = p->iterations;
     const float* in = f->v_color;
     int pp = 0;
     for (int i = 0; i < n; ++i) {
@@ -116,6 +135,9 @@ int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int r
             RMD_HIP(hipMemcpyAsync(f->hist_color_out + off, out + off, (size_t)(a1 - a0) * f->width * 16,
                                    hipMemcpyDeviceToDevice, as_stream(stream)));
         }
+        // next frame's history (hist_color_out, and t_moments since T ran before) is complete here
+        if (i == p->hist_iteration && history_ready_event)
+            RMD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(history_ready_event), as_stream(stream)));
         in = out;
     }
     return RMD_OK;

@@ -29,7 +29,10 @@ struct TemporalArgs {
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 
-__global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
+#ifndef RMD_T_MAXVGPR
+#define RMD_T_MAXVGPR 256     // experiment knob: cap T's VGPRs so its waves fit beside 3 a-trous waves per SIMD
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(RMD_T_MAXVGPR))) void svgf_temporal_kernel(TemporalArgs a)
 {
     const Geom g = a.g;
     // workgroup = one 64x4 tile of the GLOBAL tiling (rows 4k..4k+3), so T and V agree on tiles

@@ -147,9 +147,14 @@ def halo_bytes(plan: StripPlan, width):
 
 
 class ShardedDenoiser:
-    """Per-rank driver: strip plan + SvgfDenoiser + the per-frame history halo exchange."""
+    """Per-rank driver: strip plan + SvgfDenoiser + the per-frame history halo exchange.
 
-    def __init__(self, width, height, params=None, device="cuda", group=None, rank=None, world=None):
+    The halo of frame k's history is completed lazily, right before frame k+1's temporal pass and
+    on the stream that pass runs on; with pipelined=True that is the second stream, so the exchange
+    (like T and V) runs underneath frame k's remaining a-trous iterations.
+    """
+
+    def __init__(self, width, height, params=None, device="cuda", group=None, rank=None, world=None, pipelined=False):
         from . import svgf  # needs librmd.so; the plan/exchange helpers above do not
         self.svgf = svgf
         self.group = group
@@ -158,16 +163,27 @@ class ShardedDenoiser:
         self.params = params if params is not None else svgf.default_params()
         self.plan = make_plan(height, self.world, self.rank, svgf.frame_reach(self.params))
         self.width, self.height = width, height
-        self.den = svgf.SvgfDenoiser(width, height, self.plan.buf_row0, self.plan.buf_rows, self.params, device)
+        self.den = svgf.SvgfDenoiser(width, height, self.plan.buf_row0, self.plan.buf_rows, self.params, device,
+                                     pipelined=pipelined)
+        self.exchange = self.world > 1 and dist.is_initialized()
+        self._halo_pending = False
 
     def synth(self, frame_index, out=None, **kw):
         return self.svgf.synth_gbuffer(self.width, self.height, frame_index, self.plan.buf_row0, self.plan.buf_rows,
                                        out=out, **kw)
 
-    def denoise(self, color, nd, motion, out=None):
-        """Strip rows [row0,row1) of `out`; then completes next frame's history halo."""
-        out = self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1)
-        if self.world > 1:
+    def _complete_halo(self):
+        if self._halo_pending:
             hc, hm = self.den.history()
             exchange_history_halo(self.plan, hc, hm, self.group)
+            self._halo_pending = False
+
+    def denoise(self, color, nd, motion, out=None):
+        """Strip rows [row0,row1) of `out` (valid after synchronize())."""
+        out = self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1,
+                               before_tv=self._complete_halo if self.exchange else None)
+        self._halo_pending = self.exchange
         return out
+
+    def synchronize(self):
+        self.den.synchronize()

@@ -125,10 +125,15 @@ class SvgfDenoiser:
     Same plane routing as the C context (rmd_svgf_context_*), but the planes are torch tensors
     so a row-strip deployment can hand their halo rows to torch.distributed (RCCL).  Planes hold
     global rows [buf_row0, buf_row0+buf_rows); `denoise` produces rows [row0,row1).
+
+    pipelined=True software-pipelines consecutive frames over two HIP streams: T+V of frame k+1
+    (HBM-bound) is issued on a second stream as soon as frame k's history is complete (after its
+    a-trous iteration `hist_iteration`) and runs underneath frame k's remaining a-trous iterations
+    (ALU-bound).  Same kernels, same bits; results are valid after `synchronize()`.
     """
 
     def __init__(self, width, height, buf_row0=0, buf_rows=None, params=None, device="cuda", debug=False,
-                 collect_stats=False):
+                 collect_stats=False, pipelined=False):
         self.width, self.height = width, height
         self.buf_row0 = buf_row0
         self.buf_rows = height if buf_rows is None else buf_rows
@@ -149,6 +154,20 @@ class SvgfDenoiser:
         self.cur = 0
         self.has_history = False
         self.prev_nd = None
+        self.pipelined = pipelined
+        if pipelined:
+            self.stream_a = torch.cuda.Stream(device=device)      # a-trous iterations
+            self.stream_b = torch.cuda.Stream(device=device)      # T + V (+ the history halo exchange)
+            self._ev_hist, self._ev_tv = C.c_void_p(), C.c_void_p()
+            check(lib.rmd_event_create(C.byref(self._ev_hist)))
+            check(lib.rmd_event_create(C.byref(self._ev_tv)))
+            self._hist_recorded = False
+
+    def __del__(self):
+        if getattr(self, "pipelined", False):
+            for ev in (self._ev_hist, self._ev_tv):
+                if ev:
+                    lib.rmd_event_destroy(ev)
 
     def reset_history(self):
         self.has_history = False
@@ -157,6 +176,13 @@ class SvgfDenoiser:
     def history(self):
         """(hist_color, hist_moments) the NEXT denoise call reads."""
         return self.hist_color[self.cur], self.hist_moments[self.cur]
+
+    def synchronize(self):
+        if self.pipelined:
+            self.stream_a.synchronize()
+            self.stream_b.synchronize()
+        else:
+            torch.cuda.current_stream().synchronize()
 
     def describe(self, color, nd, motion, out):
         use_hist = self.has_history and self.prev_nd is not None
@@ -170,14 +196,32 @@ class SvgfDenoiser:
             v_color=self.v_color, hist_color_out=self.hist_color[self.cur ^ 1],
             ping=(self.ping[0], self.ping[1]), out_color=out, stats=self.stats, tile_flags=self.tile_flags)
 
-    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None):
-        """One frame.  `nd` is borrowed until the next call (it becomes prev_nd)."""
+    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None):
+        """One frame.  `nd` is borrowed until the next call (it becomes prev_nd).  `before_tv` is
+        called just before T is launched, on the stream T runs on (a row-strip deployment completes
+        its history halo there)."""
         if out is None:
             out = torch.empty_like(color)
         row0 = max(self.buf_row0, 0) if row0 is None else row0
         row1 = min(self.buf_row0 + self.buf_rows, self.height) if row1 is None else row1
         d = self.describe(color, nd, motion, out)
-        frame(d, self.params, row0, row1, stream)
+        if not self.pipelined:
+            if before_tv is not None:
+                before_tv()
+            frame(d, self.params, row0, row1, stream)
+        else:
+            sa, sb = self.stream_a, self.stream_b
+            sb.wait_stream(torch.cuda.current_stream())            # the caller's inputs
+            if self._hist_recorded:                                # frame k's history complete (after its A_hist)
+                check(lib.rmd_stream_wait_event(sb.cuda_stream, self._ev_hist))
+            with torch.cuda.stream(sb):
+                if before_tv is not None:
+                    before_tv()
+                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(self.params), row0, row1, sb.cuda_stream))
+            check(lib.rmd_event_record(self._ev_tv, sb.cuda_stream))
+            check(lib.rmd_stream_wait_event(sa.cuda_stream, self._ev_tv))
+            check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(self.params), row0, row1, sa.cuda_stream, self._ev_hist))
+            self._hist_recorded = True
         self.cur ^= 1
         self.has_history = True
         self.prev_nd = nd

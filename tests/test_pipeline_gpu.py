@@ -1,0 +1,99 @@
+"""Frame pipelining (two HIP streams) must not change a single bit: the same kernels run on the same
+data, only T+V of frame k+1 is issued underneath the a-trous iterations of frame k."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def run_sequence(rmd, width, height, frames, pipelined, p):
+    den = rmd.SvgfDenoiser(width, height, params=p, pipelined=pipelined)
+    inputs = [rmd.svgf.synth_gbuffer(width, height, f) for f in range(frames)]
+    torch.cuda.synchronize()
+    outs = [torch.empty_like(inputs[0][0]) for _ in range(frames)]
+    for f in range(frames):                                   # no host sync between frames
+        c, nd, m = inputs[f]
+        den.denoise(c, nd, m, outs[f])
+    den.synchronize()
+    torch.cuda.synchronize()
+    return outs, den
+
+
+@pytest.mark.parametrize("width,height", [(300, 200), (1920, 1080)])
+def test_pipelined_frames_equal_serial_frames(rmd, cuda, width, height):
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    serial, den_s = run_sequence(rmd, width, height, 8, False, p)
+    piped, den_p = run_sequence(rmd, width, height, 8, True, p)
+    for f, (a, b) in enumerate(zip(serial, piped)):
+        assert torch.equal(a, b), f"frame {f}: {(a != b).sum().item()} values differ"
+    for a, b in zip(den_s.history(), den_p.history()):
+        assert torch.equal(a, b)
+
+
+def test_pipelined_repeatable(rmd, cuda):
+    """Race check: many frames, several runs, always the same bits."""
+    p = rmd.default_params()
+    ref, _ = run_sequence(rmd, 640, 360, 12, True, p)
+    for _ in range(3):
+        again, _ = run_sequence(rmd, 640, 360, 12, True, p)
+        assert all(torch.equal(a, b) for a, b in zip(ref, again))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, width, height, frames, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import raymarchdenoisercuda_amd as rmd
+        from raymarchdenoisercuda_amd import sharding
+        torch.cuda.set_device(0)
+        p = rmd.default_params()
+        p.max_motion_rows = 8
+        sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world, pipelined=True)
+        single = rmd.SvgfDenoiser(width, height, params=p)
+        strips = [sd.synth(f) for f in range(frames)]
+        outs = [torch.empty_like(strips[0][0]) for _ in range(frames)]
+        torch.cuda.synchronize()
+        for f in range(frames):
+            sd.denoise(*strips[f], outs[f])
+        sd.synchronize()
+        ok = True
+        a, b = sd.plan.row0, sd.plan.row1
+        for f in range(frames):
+            c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
+            want = single.denoise(c, nd, m)
+            torch.cuda.synchronize()
+            ok = ok and torch.equal(outs[f][a - sd.plan.buf_row0:b - sd.plan.buf_row0], want[a:b])
+        result[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_row_strips_over_torch_distributed(cuda):
+    """Two ranks (sharing cuda:0 over gloo), pipelined, halo exchange on the T stream: strips still
+    equal the single-device frames bit for bit."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    result = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 160, 420, 5, result)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert [result.get(r) for r in range(world)] == [True] * world
