@@ -115,14 +115,16 @@ __device__ __forceinline__ void make_center(const Tap& t, float var_c, float gz,
     k.nx = t.n.x; k.ny = t.n.y; k.nz = t.n.z; k.z = t.n.w;
     k.lum = t.c.x;
     x.zero = is_zero3(t.n);
+    // log2e / (a*len + 1e-8) is evaluated as 1 / (a*(len/log2e) + 1e-8/log2e): one fma + one v_rcp_f32
+    constexpr float kInvLog2e = 1.0f / kLog2e, kEps = 1e-8f / kLog2e;
     const float vc = var_c > 0.0f ? var_c : 0.0f;
-    k.il = kLog2e * fast_rcp(fma_(sigma_l, __builtin_amdgcn_sqrtf(vc), 1e-8f));
+    k.il = fast_rcp(fma_(sigma_l * kInvLog2e, __builtin_amdgcn_sqrtf(vc), kEps));
     const float za = sigma_z * fmaxf(gz, 1e-8f) * step;
-    x.iz[0] = kLog2e * fast_rcp(za + 1e-8f);
-    x.iz[1] = kLog2e * fast_rcp(fma_(za, 1.41421356237309504880f, 1e-8f));
-    x.iz[2] = kLog2e * fast_rcp(fma_(za, 2.0f, 1e-8f));
-    x.iz[3] = kLog2e * fast_rcp(fma_(za, 2.23606797749978969641f, 1e-8f));
-    x.iz[4] = kLog2e * fast_rcp(fma_(za, 2.82842712474619009760f, 1e-8f));
+    x.iz[0] = fast_rcp(fma_(za, 1.0f * kInvLog2e, kEps));
+    x.iz[1] = fast_rcp(fma_(za, 1.41421356237309504880f * kInvLog2e, kEps));
+    x.iz[2] = fast_rcp(fma_(za, 2.0f * kInvLog2e, kEps));
+    x.iz[3] = fast_rcp(fma_(za, 2.23606797749978969641f * kInvLog2e, kEps));
+    x.iz[4] = fast_rcp(fma_(za, 2.82842712474619009760f * kInvLog2e, kEps));
 }
 
 __device__ __forceinline__ f2 pair_of(float a, float b)
