@@ -12,7 +12,7 @@ LIB      := $(LIBDIR)/librmd.so
 
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-variable \
             -Wno-unused-but-set-variable
-KERNELS  := $(CSRC)/runtime.hip $(CSRC)/box_filter.hip $(CSRC)/svgf_temporal.hip $(CSRC)/svgf_variance.hip \
+KERNELS  := $(CSRC)/runtime.hip $(CSRC)/box_filter.hip $(CSRC)/weighted_filter.hip $(CSRC)/svgf_temporal.hip $(CSRC)/svgf_variance.hip \
             $(CSRC)/svgf_atrous.hip $(CSRC)/svgf_frame.hip $(CSRC)/convert_synth.hip
 OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(KERNELS))
 

@@ -84,9 +84,15 @@ int rmd_filter_baseline(rmd_gbuffer frame, rmd_filter_params params, void* strea
  * tile+halo in LDS (the job of reference cacheTile, src/filter.cu:60-85) with a consistent
  * stride, so both settings give the cacheInput=false result (the reference's cacheInput=true
  * output is corrupted by a stride mismatch, SURVEY §0.2, and is not a parity target).
- * params.type selects AVERAGE (reference behaviour) or the declared-but-unimplemented
- * GAUSSIAN / CROSS / WAVELET modes (include/filter.cuh:12-19); those return
- * RMD_E_UNSUPPORTED until built. */
+ * params.type selects AVERAGE (reference behaviour) or the modes the reference declares but never
+ * implements (include/filter.cuh:12-19; every kernel there uses w = 1):
+ *   GAUSSIAN  w = exp(-(dx^2+dy^2)/(2 sigmaSpace^2)) over the (2r+1)^2 window
+ *   CROSS     GAUSSIAN x exp(-|dc|^2/(2 sigmaColor^2)) x exp(-|da|^2/(2 sigmaAlbedo^2)) x
+ *             exp(-|dn|^2/(2 sigmaNormal^2)) with c = the level's input plane, a / n = frame.albedo /
+ *             frame.normal (0..255 units; a term with sigma <= 0 or a NULL plane is dropped)
+ *   WAVELET   5x5 B3-spline taps {3/8,1/4,1/16} (src/filter.cu:10) at spacing 2^(level + l) for level
+ *             index l, times the CROSS edge terms (edge-avoiding a-trous on the 8-bit planes)
+ * Parity for these three is unpinned by the reference (csrc/weighted_filter.hip). */
 int rmd_filter_tiled(rmd_gbuffer frame, rmd_filter_params params, void* stream);
 
 /* ---- SVGF (north_star hot path; the reference only names it: README.md:3-10) ------------ */

@@ -3,6 +3,7 @@
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  Pinned by SURVEY §8(c) SHA-256 known answers.
  */
 #include "oracle.h"
+#include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
@@ -74,6 +75,58 @@ void orc_box_filter_mt(const uint8_t* render, uint8_t* denoised, int W, int H, i
     box_worker(&jobs[threads - 1]);
     for (int t = 0; t + 1 < threads; ++t) pthread_join(th[t], NULL);
     free(th); free(jobs);
+}
+
+/* FilterParams::type GAUSSIAN / CROSS / WAVELET.  PARITY UNPINNED BY THE REFERENCE: it declares the
+ * modes (include/filter.cuh:12-19) and the B3 taps (src/filter.cu:10) but every kernel uses w = 1
+ * (src/filter.cu:41,127).  Semantics: see raymarchdenoisercuda_amd/csrc/weighted_filter.hip; kept
+ * from the reference: level ping-pong, tap order, OOB skip + renormalise, truncating cast. */
+static float dist2_u8(const uint8_t* a, const uint8_t* b)
+{
+    float dx = (float)a[0] - (float)b[0], dy = (float)a[1] - (float)b[1], dz = (float)a[2] - (float)b[2];
+    return dx * dx + dy * dy + dz * dz;
+}
+
+static float inv2s(float sigma) { return sigma > 0.0f ? 1.0f / (2.0f * sigma * sigma) : 0.0f; }
+
+void orc_weighted_filter(const uint8_t* render, uint8_t* denoised, uint8_t* buf0, uint8_t* buf1,
+                         const uint8_t* normal, const uint8_t* albedo, int W, int H, const rmd_filter_params* p)
+{
+    static const float spline[3] = { 0.375f, 0.25f, 0.0625f };
+    uint8_t* buf[2] = { buf0, buf1 };
+    const int mode = p->type;
+    const float is_s = inv2s(p->sigmaSpace), is_c = inv2s(p->sigmaColor), is_a = inv2s(p->sigmaAlbedo), is_n = inv2s(p->sigmaNormal);
+    if (mode == RMD_FILTER_GAUSSIAN || !(p->sigmaNormal > 0.0f)) normal = NULL;
+    if (mode == RMD_FILTER_GAUSSIAN || !(p->sigmaAlbedo > 0.0f)) albedo = NULL;
+    for (int level = 0; level < p->depth; ++level) {
+        const uint8_t* in = (level == 0) ? render : buf[level % 2];
+        uint8_t* out = (level == p->depth - 1) ? denoised : buf[(level + 1) % 2];
+        const int radius = mode == RMD_FILTER_WAVELET ? 2 : p->radius;
+        const int step = mode == RMD_FILTER_WAVELET ? (1 << (p->level + level)) : 1;
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const size_t i = ((size_t)y * W + x) * 4;
+                float sr = 0.0f, sg = 0.0f, sb = 0.0f, sw = 0.0f;
+                for (int dx = -radius; dx <= radius; ++dx)
+                    for (int dy = -radius; dy <= radius; ++dy) {
+                        int tx = x + dx * step, ty = y + dy * step;
+                        if (tx < 0 || tx >= W || ty < 0 || ty >= H) continue;
+                        const size_t t = ((size_t)ty * W + tx) * 4;
+                        float e = 0.0f, k = 1.0f;
+                        if (mode == RMD_FILTER_WAVELET) k = spline[dx < 0 ? -dx : dx] * spline[dy < 0 ? -dy : dy];
+                        else e = (float)(dx * dx + dy * dy) * is_s;
+                        if (mode != RMD_FILTER_GAUSSIAN) {
+                            e += dist2_u8(in + i, in + t) * is_c;
+                            if (albedo) e += dist2_u8(albedo + i, albedo + t) * is_a;
+                            if (normal) e += dist2_u8(normal + i, normal + t) * is_n;
+                        }
+                        float w = k * expf(-e);
+                        sr += w * (float)in[t]; sg += w * (float)in[t + 1]; sb += w * (float)in[t + 2];
+                        sw += w;
+                    }
+                out[i] = (uint8_t)(sr / sw); out[i + 1] = (uint8_t)(sg / sw); out[i + 2] = (uint8_t)(sb / sw); out[i + 3] = 0;
+            }
+    }
 }
 
 int orc_hardware_threads(void)

@@ -184,9 +184,8 @@ int rmd_filter_baseline(rmd_gbuffer frame, rmd_filter_params params, void* strea
 int rmd_filter_tiled(rmd_gbuffer frame, rmd_filter_params params, void* stream)
 {
     if (int e = validate(frame, params, "rmd_filter_tiled")) return e;
-    if (params.type != RMD_FILTER_AVERAGE)
-        return fail(RMD_E_UNSUPPORTED, "rmd_filter_tiled: filter type %d is declared by the reference (include/filter.cuh:12) "
-                                       "but implemented by neither it nor this build yet", params.type);
+    if (params.type != RMD_FILTER_AVERAGE)     // GAUSSIAN / CROSS / WAVELET: csrc/weighted_filter.hip
+        return run_weighted_levels(frame, params, as_stream(stream));
     const bool lds_ok = params.radius <= kMaxExactRadius && box_lds_bytes(params.radius) <= 64 * 1024;
     return run_levels<false>(frame, params, params.cacheInput && lds_ok, as_stream(stream));
 }

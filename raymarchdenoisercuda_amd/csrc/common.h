@@ -51,6 +51,8 @@ int check_rows_in_buffer(const rmd_svgf_frame_desc* f, int lo, int hi, const cha
 // pixels on the spatial path (saves 32 B/px of the 64 B/px V would move).
 // With f->v_tile_flags set, T also marks the 64x4 tiles (global tiling) that hold short-history
 // pixels and V returns at once from every unmarked tile.
+// FilterParams::type GAUSSIAN / CROSS / WAVELET on the uchar4 planes (csrc/weighted_filter.hip)
+int run_weighted_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStream_t stream);
 int launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
 int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
 

@@ -84,6 +84,19 @@ def box_filter(render_rgba: np.ndarray, radius=2, depth=1, gray_from_r=False, th
     return out
 
 
+def weighted_filter(render_rgba: np.ndarray, params, normal=None, albedo=None) -> np.ndarray:
+    """FilterParams::type GAUSSIAN / CROSS / WAVELET (`params` = the ctypes FilterParams)."""
+    src = np.ascontiguousarray(render_rgba)
+    h, w, _ = src.shape
+    out, b0, b1 = np.zeros_like(src), np.zeros_like(src), np.zeros_like(src)
+    nrm = None if normal is None else np.ascontiguousarray(normal)
+    alb = None if albedo is None else np.ascontiguousarray(albedo)
+    lib.orc_weighted_filter.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
+    lib.orc_weighted_filter.restype = None
+    lib.orc_weighted_filter(_p(src), _p(out), _p(b0), _p(b1), _p(nrm), _p(alb), w, h, C.byref(params))
+    return out
+
+
 # ---- SVGF ------------------------------------------------------------------------------------
 class Frame:
     """Host planes of one SVGF frame (numpy float32) + the descriptor the oracle reads."""

@@ -67,8 +67,11 @@ def test_argument_errors_are_reported_without_a_gpu(rmd):
         rmd.filterKernelTiled(g, rmd.FilterParams(radius=-1))
     assert e.value.code == -3
     with pytest.raises(rmd.RmdError) as e:
-        rmd.filterKernelTiled(g, rmd.FilterParams(type=rmd.FilterParams.WAVELET))
-    assert e.value.code == -6
+        rmd.filterKernelTiled(g, rmd.FilterParams(type=7))                       # not a FilterType
+    assert e.value.code == -3
+    with pytest.raises(rmd.RmdError) as e:
+        rmd.filterKernelTiled(g, rmd.FilterParams(type=rmd.FilterParams.GAUSSIAN, sigmaSpace=0.0))
+    assert e.value.code == -3
     d = rmd.SvgfFrameDesc()
     d.width, d.height, d.buf_row0, d.buf_rows = 16, 16, 4, 20
     with pytest.raises(rmd.RmdError) as e:
