@@ -81,16 +81,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(RMD_T_MAXVGPR))
             inb[k] = tx >= 0 && tx < g.W && ty >= 0 && ty < g.H && abs(ty - y) <= a.max_motion_rows;
             ti[k] = pix_index(g, min(max(tx, 0), g.W - 1), min(max(ty, ylo), yhi));
         }
+        // Two batches: the four prev_nd gathers decide tap validity; only then the eight
+        // hist_color / hist_moments gathers are issued.  The fence keeps the register footprint at
+        // <= 56 VGPRs, so that one wave of this kernel fits on a SIMD beside three a-trous waves
+        // (3 x 152 of 512 registers) when frames are pipelined over two streams.
 #pragma unroll
         for (int k = 0; k < 4; ++k) pn[k] = a.prev_nd[ti[k]];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool ok_n = p_zero ? is_zero3(pn[k]) : ((pn[k].x * nd.x + pn[k].y * nd.y + pn[k].z * nd.z) >= a.k_n);
+            ok[k] = inb[k] && (fabsf(pn[k].w - nd.w) <= zthr) && ok_n;
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < 4; ++k) { hc[k] = a.hist_color[ti[k]]; hm[k] = a.hist_moments[ti[k]]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (!inb[k]) continue;
-            if (!(fabsf(pn[k].w - nd.w) <= zthr)) continue;
-            const bool ok_n = p_zero ? is_zero3(pn[k]) : ((pn[k].x * nd.x + pn[k].y * nd.y + pn[k].z * nd.z) >= a.k_n);
-            if (!ok_n) continue;
+            if (!ok[k]) continue;
             mask |= 1 << k;
             const float w = wk[k];
             wsum += w;
