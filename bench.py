@@ -160,9 +160,11 @@ def main():
     p = rmd.default_params()
     p.max_motion_rows = 8            # the synthetic pan moves <= 1.5 rows per frame
     p.atrous_variant = int(os.environ.get("RMD_ATROUS_VARIANT", "0"))   # 0 = library default (experiments only)
-    # consecutive frames are software-pipelined over two HIP streams (T+V of frame k+1 under the
-    # a-trous iterations of frame k); RMD_PIPELINE=0 runs the 7 launches of a frame back to back
-    pipelined = os.environ.get("RMD_PIPELINE", "1") != "0"
+    # Default: the 7 launches of a frame back to back on one stream, so the per-kernel durations of a
+    # rocprofv3 run of this command are those of isolated launches (what `roofline` prices).
+    # RMD_PIPELINE=1 software-pipelines consecutive frames over two HIP streams (T+V of frame k+1
+    # under the a-trous iterations of frame k): +4 % frames/s, but the overlapped launches share CUs.
+    pipelined = os.environ.get("RMD_PIPELINE", "0") == "1"
     sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world, pipelined=pipelined)
     plan = sd.plan
     rows_out = plan.row1 - plan.row0
