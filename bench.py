@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-sizes", action="store_true")
     ap.add_argument("--roofline-reps", type=int, default=30)
     return ap.parse_args()
 
@@ -96,6 +97,23 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps):
         "atrous_x5_ms": round(sum(per_iter), 5),
         "atrous_x5_mpix_s": round(px / (sum(per_iter) * 1e-3) / 1e6, 1),
     }
+
+
+def other_size(rmd, torch, width, height, p, frames=16, warm=4):
+    """Full SVGF Mpixels/s at another frame size: `warm` + `frames` frames of the synthetic sequence."""
+    den = rmd.SvgfDenoiser(width, height, params=p)
+    seq = [rmd.svgf.synth_gbuffer(width, height, f) for f in range(warm + frames)]
+    out = torch.empty_like(seq[0][0])
+    for f in range(warm):
+        den.denoise(*seq[f], out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(warm, warm + frames):
+        den.denoise(*seq[f], out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"mpix_s": round(width * height * frames / dt / 1e6, 1), "ms_per_frame": round(dt / frames * 1e3, 4),
+            "effective_GBps": round(FULL_BYTES_PER_PX * width * height * frames / dt / 1e9, 1), "frames": frames}
 
 
 def cpu_baseline():
@@ -164,7 +182,9 @@ def main():
     # rocprofv3 run of this command are those of isolated launches (what `roofline` prices).
     # RMD_PIPELINE=1 software-pipelines consecutive frames over two HIP streams (T+V of frame k+1
     # under the a-trous iterations of frame k): +4 % frames/s, but the overlapped launches share CUs.
-    pipelined = os.environ.get("RMD_PIPELINE", "0") == "1"
+    # With N > 1 the second stream is on by default: it carries the RCCL history halo exchange, which
+    # then runs underneath the a-trous iterations instead of in front of the next frame.
+    pipelined = os.environ.get("RMD_PIPELINE", "1" if world > 1 else "0") == "1"
     sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world, pipelined=pipelined)
     plan = sd.plan
     rows_out = plan.row1 - plan.row0
@@ -219,6 +239,11 @@ def main():
 
     if rank == 0:
         result["roofline"] = measure_roofline(rmd, torch, sd.den, frames, width, rows_out, plan, args.roofline_reps)
+    if world == 1 and not args.no_other_sizes:
+        # the other frame sizes north_star names, same pipeline, short runs (not the headline value)
+        del frames, sd
+        torch.cuda.empty_cache()
+        result["other_sizes"] = {f"{w}x{h}": other_size(rmd, torch, w, h, p) for w, h in ((1920, 1080), (7680, 4320))}
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
