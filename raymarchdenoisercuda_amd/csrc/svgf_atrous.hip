@@ -47,6 +47,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define RMD_ATROUS_GROUP_ROWS 2   // window rows per scheduling group of the tap loop (1, 2, 3 or 6)
 #endif
 
+#ifndef RMD_PRIO_T1               // a wave's priority drops 3 -> 2 -> 1 -> 0 once T1/16, T2/16, T3/16 of its rows are done
+#define RMD_PRIO_T1 8
+#define RMD_PRIO_T2 12
+#define RMD_PRIO_T3 14
+#endif
+
 struct AtrousArgs {
     Geom g;
     const float4* in; const float4* nd; float4* out;
@@ -142,38 +148,61 @@ __device__ __forceinline__ Center<f2> pack(const Center<float> a, const Center<f
     return k;
 }
 
+// Three packed forms the compiler does not pick by itself, spelled as VOP3P instructions.  `b` is the
+// (z, w) half of a staged float4; the values are exactly those of the generic C++ forms.
+//   - the [0,1] clamp as the clamp bit of the last packed fma of the cosine (the compiler only folds
+//     it into scalar v_fma_f32 and otherwise spends two v_max_f32 per pair);
+//   - broadcasting the HIGH half of b (the tap depth, .w) through op_sel instead of a v_mov_b32 first.
+//     (The same form for the variance accumulation costs registers the kernel does not have: 168
+//     VGPRs + scratch, so that one keeps its v_mov_b32.)
+__device__ __forceinline__ f2 pk_fma_lo_clamp(f2 a, f2 b, f2 c)        // clamp01(a * b.lo + c)
+{
+    f2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ f2 pk_sub_hi(f2 a, f2 b)                    // a - b.hi
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // clamp01(n_p . n_t): the same three operations for one pixel (float) and for the pair (f2)
 template <class T>
 __device__ __forceinline__ T tap_cosine(const Center<T>& k, const Tap& t)
 {
     T d = k.nx * bc(t.n.x, T{});
     d = fma_(k.ny, bc(t.n.y, T{}), d);
-    return clamp01(fma_(k.nz, bc(t.n.z, T{}), d));
+    if constexpr (std::is_same<T, f2>::value) return pk_fma_lo_clamp(k.nz, f2{ t.n.z, t.n.w }, d);
+    else return clamp01(fma_(k.nz, bc(t.n.z, T{}), d));
 }
 
 // One pixel's exponent, scalar on purpose: v_fma_f32 takes |.| and - as free source modifiers and
 // e0 as a literal (packed f32 has neither, and a packed e0 would need a VGPR pair per tap):
-//   e = e0 + sigma_n*log2(cos) - |z_p - z_t|*iz - |l_p - l_t|*il
+//   e = e0 + sigma_n*log2(cos) - |dz|*iz - |dl|*il,   dz = z_p - z_t, dl = l_p - l_t
+// The differences themselves come in from the caller: for the (A,B) pair they are one v_pk_add_f32
+// each (negated broadcast tap value), read back here as the two halves of the result.
 template <bool ZERO_AWARE>
-__device__ __forceinline__ float tap_exponent(float cosine, float e0, float sigma_n, float zp, float lp, float il,
-                                              const CenterAux& x, const Tap& t, bool tap_zero, int adx, int ady)
+__device__ __forceinline__ float tap_exponent(float cosine, float e0, float sigma_n, float dz, float dl, float il,
+                                              const CenterAux& x, bool tap_zero, int adx, int ady)
 {
     float e = fma_(sigma_n, log2_(cosine), e0);
     if (ZERO_AWARE) {   // Appendix A.A.2: both normals zero => w_n = 1, exactly one zero => 0
         if (x.zero) e = tap_zero ? e0 : kNegInf;
     }
-    if (adx | ady) e = fma_(-fabsf(zp - t.n.w), x.iz[len_class(adx, ady)], e);
-    return fma_(-fabsf(lp - t.c.x), il, e);
+    if (adx | ady) e = fma_(-fabsf(dz), x.iz[len_class(adx, ady)], e);
+    return fma_(-fabsf(dl), il, e);
 }
 
 template <class T>
-__device__ __forceinline__ void tap_accumulate(Acc<T>& s, T w, const Tap& t)
+__device__ __forceinline__ void tap_accumulate(Acc<T>& s, T w, float lum, float r, float g, float var)
 {
     s.sw += w;
-    s.sl = fma_(w, bc(t.c.x, T{}), s.sl);
-    s.sr = fma_(w, bc(t.c.y, T{}), s.sr);
-    s.sg = fma_(w, bc(t.c.z, T{}), s.sg);
-    s.sv = fma_(w * w, bc(t.c.w, T{}), s.sv);
+    s.sl = fma_(w, bc(lum, T{}), s.sl);
+    s.sr = fma_(w, bc(r, T{}), s.sr);
+    s.sg = fma_(w, bc(g, T{}), s.sg);
+    s.sv = fma_(w * w, bc(var, T{}), s.sv);
 }
 
 // one pixel, one tap
@@ -181,9 +210,9 @@ template <bool ZERO_AWARE>
 __device__ __forceinline__ void tap_single(Acc<float>& s, const Center<float>& k, const CenterAux& x, const Tap& t,
                                            float e0, int adx, int ady, float sigma_n)
 {
-    const float e = tap_exponent<ZERO_AWARE>(tap_cosine<float>(k, t), e0, sigma_n, k.z, k.lum, k.il, x, t,
+    const float e = tap_exponent<ZERO_AWARE>(tap_cosine<float>(k, t), e0, sigma_n, k.z - t.n.w, k.lum - t.c.x, k.il, x,
                                              ZERO_AWARE && is_zero3(t.n), adx, ady);
-    tap_accumulate<float>(s, exp2_(e), t);
+    tap_accumulate<float>(s, exp2_(e), t.c.x, t.c.y, t.c.z, t.c.w);
 }
 
 // the (A,B) pair sharing one tap: adyA / adyB are the tap's |row offset| seen from A and from B.
@@ -195,11 +224,12 @@ __device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const 
 {
     const f2 c = tap_cosine<f2>(k, t);
     const bool tz = ZERO_AWARE && is_zero3(t.n);
-    float ca = c.x, cb = c.y;
-    asm("" : "+v"(ca), "+v"(cb));
-    const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, k.z.x, k.lum.x, k.il.x, xa, t, tz, adx, adyA);
-    const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, k.z.y, k.lum.y, k.il.y, xb, t, tz, adx, adyB);
-    tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t);
+    const f2 dz = pk_sub_hi(k.z, f2{ t.n.z, t.n.w }), dl = k.lum - bc(t.c.x, f2{});
+    float ca = c.x, cb = c.y, dza = dz.x, dzb = dz.y, dla = dl.x, dlb = dl.y;
+    asm("" : "+v"(ca), "+v"(cb), "+v"(dza), "+v"(dzb), "+v"(dla), "+v"(dlb));
+    const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, dza, dla, k.il.x, xa, tz, adx, adyA);
+    const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, dzb, dlb, k.il.y, xb, tz, adx, adyB);
+    tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t.c.x, t.c.y, t.c.z, t.c.w);
 }
 
 // A.A.3.  c = the centre in (lum, r, g, var) form.
@@ -579,7 +609,18 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     store_aux();
     __syncthreads();
 
+    // The SIMD arbiter issues oldest-wave-first.  With three VALU-bound workgroups on a CU that
+    // lets the oldest finish at ~half the kernel time and the youngest run its second half with
+    // one wave per SIMD, which cannot fill the VALU (tools/atrous_trace.py: end times spread over
+    // 80..155 us).  Lowering a wave's priority as ITS work completes makes the three workgroups
+    // advance together, so the CU keeps three waves per SIMD until nearly the end.
+    const int span = jhi - j0;
+    const int jq1 = j0 + span * RMD_PRIO_T1 / 16, jq2 = j0 + span * RMD_PRIO_T2 / 16, jq3 = j0 + span * RMD_PRIO_T3 / 16;
+    __builtin_amdgcn_s_setprio(3);
     for (int j = j0; j < jhi; j += C::ADV) {
+        if (j >= jq3)      __builtin_amdgcn_s_setprio(0);
+        else if (j >= jq2) __builtin_amdgcn_s_setprio(1);
+        else if (j >= jq1) __builtin_amdgcn_s_setprio(2);
         const bool more = j + C::ADV < jhi;
         if (more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute
         compute(j);
@@ -591,9 +632,18 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     }
 }
 
+#ifdef RMD_ATROUS_TRACE
+// tuning aid (tools/build_variant.sh trace -DRMD_ATROUS_TRACE): per-workgroup start / end time
+// (100 MHz s_memrealtime), placement (XCC_ID, HW_ID) and code path of the LAST stream launch
+__device__ unsigned long long g_atrous_trace[4 * 8192];
+#endif
+
 template <int S, int NP>
 __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(AtrousArgs a)
 {
+#ifdef RMD_ATROUS_TRACE
+    const unsigned long long trace_t0 = wall_clock64();
+#endif
     using C = StreamCfg<S, NP>;
     extern __shared__ __attribute__((aligned(16))) unsigned char atrous_lds[];
     const int tid = threadIdx.x;
@@ -620,7 +670,31 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(A
     const bool edge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W) || ytop < blo || ybot >= bhi;
     if (edge) atrous_stream_body<S, NP, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
     else      atrous_stream_body<S, NP, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+#ifdef RMD_ATROUS_TRACE
+    __syncthreads();
+    if (tid == 0 && pid < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_atrous_trace[4 * pid + 0] = trace_t0;
+        g_atrous_trace[4 * pid + 1] = wall_clock64();
+        g_atrous_trace[4 * pid + 2] = ((unsigned long long)xcc << 32) | hw;
+        g_atrous_trace[4 * pid + 3] = ((unsigned long long)L << 8) | (edge ? 1u : 0u);
+    }
+#endif
 }
+
+#ifdef RMD_ATROUS_TRACE
+extern "C" int rmd_debug_atrous_trace(unsigned long long* host_dst, int workgroups)
+{
+    RMD_HIP(hipDeviceSynchronize());
+    RMD_HIP(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_atrous_trace), sizeof(unsigned long long) * 4 * (size_t)workgroups));
+    void* dev = nullptr;                                   // cleared on read: the next read sees one launch only
+    RMD_HIP(hipGetSymbolAddress(&dev, HIP_SYMBOL(g_atrous_trace)));
+    RMD_HIP(hipMemset(dev, 0, sizeof(g_atrous_trace)));
+    return RMD_OK;
+}
+#endif
 
 template <int S, int NP>
 static int launch_stream(AtrousArgs a, hipStream_t stream)
@@ -641,6 +715,7 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
     // ceil(workgroups / resident slots) rounds; pick the band count that fills the rounds best,
     // discounted by the 4 halo rows each workgroup stages on top of its own lattice rows.
     const int slots = C::WG_PER_CU * kCus;
+    static const int min_rounds = [] { const char* e = getenv("RMD_ATROUS_MIN_ROUNDS"); return e ? atoi(e) : 1; }();
     int bh = ((rows + unit - 1) / unit) * unit;
     double best = -1.0;
     for (int nb = 1; nb <= 64; ++nb) {
@@ -651,6 +726,7 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
         const int rounds = (wgs + slots - 1) / slots;
         const double lattice_rows = (double)h / S;
         const double eff = (double)wgs / ((double)rounds * slots) * lattice_rows / (lattice_rows + 4.0);
+        if (rounds < min_rounds && h > unit) continue;
         if (eff > best + 1e-9) { best = eff; bh = h; }
         if (h == unit) break;
     }

@@ -217,6 +217,26 @@ def test_cornell_full_svgf(rmd, orc, cuda):
         close(out, fr.out_color, TOL_FRAME, f"cornell frame {f}")
 
 
+def test_cornell_tiled_to_1080p(rmd, orc, cuda):
+    """BASELINE config 2 shape: 1920x1080 Cornell (the 500x500 planes tiled 4x3 and cropped; the
+    reference ships no larger frame).  Full SVGF, 2 frames with a 1.25/-0.5 px pan so reprojection,
+    disocclusion at the tile seams and the zero-normal background all occur at full size."""
+    color, nd, motion = orc.cornell_svgf_inputs()
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (3, 4, 1))[:1080, :1920])  # noqa: E731
+    color, nd = tile(color), tile(nd)
+    motion = np.zeros((1080, 1920, 2), np.float32)
+    motion[..., 0], motion[..., 1] = 1.25, -0.5
+    p = orc.default_params()
+    ref = oracle_sequence(orc, 1920, 1080, 2, p, inputs=[(color, nd, motion)] * 2)
+    den = rmd.SvgfDenoiser(1920, 1080, params=p, debug=True)
+    for f, fr in enumerate(ref):
+        out = den.denoise(dev(color), dev(nd), dev(motion))
+        torch.cuda.synchronize()
+        assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}: integer outputs"
+        close(out, fr.out_color, TOL_FRAME, f"cornell 1080p frame {f}")
+    assert (ref[1].t_debug[..., 3] == 2).mean() > 0.5 and (ref[1].t_debug[..., 3] == 1).any()
+
+
 def test_c_context_matches_python_denoiser(rmd, cuda):
     """rmd_svgf_context_* (the C-side owner of the history planes) gives the same frames."""
     import ctypes as C

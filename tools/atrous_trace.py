@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-workgroup timeline of one a-trous launch (tuning aid, needs the trace build):
+    tools/build_variant.sh trace -DRMD_ATROUS_TRACE
+    RMD_LIB_PATH=build/variants/librmd_trace.so python3 tools/atrous_trace.py
+Prints, per iteration, how the workgroups spread over XCDs / CUs, when they start and end
+(100 MHz ticks = 10 ns), and the duration split of interior vs frame-edge workgroups."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import raymarchdenoisercuda_amd as rmd  # noqa: E402
+
+W, H = (int(os.environ.get("PROBE_W", 3840)), int(os.environ.get("PROBE_H", 2160)))
+raw = C.CDLL(rmd.LIB_PATH)
+p = rmd.default_params()
+p.max_motion_rows = 8
+den = rmd.SvgfDenoiser(W, H, params=p)
+frames = [rmd.svgf.synth_gbuffer(W, H, f) for f in range(3)]
+for c, nd, m in frames:
+    den.denoise(c, nd, m)
+torch.cuda.synchronize()
+c, nd, m = frames[-1]
+desc = den.describe(c, nd, m, den.ping[1])
+NWG = 8192
+buf = np.zeros((NWG, 4), np.uint64)
+src, dst = den.v_color, den.ping[0]
+for it in range(5):
+    for rep in range(2):                      # warm, then the launch that is read back (read clears)
+        rmd.svgf.atrous(desc, p, it, src, dst, 0, H)
+        assert raw.rmd_debug_atrous_trace(buf.ctypes.data_as(C.c_void_p), NWG) == 0
+    src, dst = dst, (den.ping[1] if dst is den.ping[0] else den.ping[0])
+    t = buf[buf[:, 0] > 0]
+    t0 = t[:, 0].min()
+    start, end = (t[:, 0] - t0).astype(np.int64), (t[:, 1] - t0).astype(np.int64)
+    dur = end - start
+    hw, xcc = (t[:, 2] & 0xFFFFFFFF).astype(np.int64), (t[:, 2] >> 32).astype(np.int64) & 0xF
+    cu = (hw >> 8) & 0xF
+    sh = (hw >> 12) & 0x1
+    se = (hw >> 13) & 0x7
+    edge = (t[:, 3] & 1).astype(bool)
+    cu_key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    per_cu = np.bincount(np.unique(cu_key, return_inverse=True)[1])
+    print(f"--- iteration {it} (step {1 << it}): {len(t)} workgroups, kernel span {end.max() / 100:.1f} us")
+    print(f"    distinct CUs {len(per_cu)}, workgroups per CU min/max {per_cu.min()}/{per_cu.max()}, histogram {np.bincount(per_cu).tolist()}")
+    print(f"    per XCD: {np.bincount(xcc, minlength=8).tolist()}")
+    print(f"    start  us: p50 {np.percentile(start, 50) / 100:.1f}  p90 {np.percentile(start, 90) / 100:.1f}  max {start.max() / 100:.1f}")
+    print(f"    end    us: p10 {np.percentile(end, 10) / 100:.1f}  p50 {np.percentile(end, 50) / 100:.1f}  p90 {np.percentile(end, 90) / 100:.1f}  max {end.max() / 100:.1f}")
+    for name, sel in (("interior", ~edge), ("edge", edge)):
+        if sel.any():
+            d = dur[sel] / 100.0
+            print(f"    {name:8s} n={sel.sum():4d} duration us: min {d.min():.1f}  p50 {np.percentile(d, 50):.1f}  p90 {np.percentile(d, 90):.1f}  max {d.max():.1f}")
+    late = start > np.percentile(end, 10)
+    print(f"    workgroups that start after the first 10% have ended: {late.sum()}")
+    occ = (dur.sum() / max(end.max(), 1)) / (len(per_cu) * 3)
+    print(f"    average resident workgroups / (CUs x 3): {occ:.3f}")
