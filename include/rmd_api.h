@@ -118,7 +118,9 @@ typedef struct rmd_svgf_params {
     int   iterations;       /* 5   step 2^i for i in [0, iterations)                           */
     int   hist_iteration;   /* 0   output of this iteration becomes next frame's hist_color    */
     int   atrous_variant;   /* 0 auto | 1 direct (global loads) | 2 LDS row-streaming           */
-    int   reserved0;
+    int   tv_workgroups;    /* 0   T and V as one workgroup per 64x4 tile (default, fastest) | N > 0: N persistent
+                                   workgroups that walk the tiles: a constant register footprint beside another
+                                   frame's a-trous launches (experimental, slower so far); same results either way */
     int   reserved1;
 } rmd_svgf_params;
 
@@ -152,11 +154,11 @@ typedef struct rmd_svgf_frame_desc {
                                   [0] sum of variance, [1] pixels on the spatial path,
                                   [2] sum of history length, [3] pixels processed              */
     unsigned char* v_tile_flags; /* optional scratch used by rmd_svgf_frame: one byte per 64x4-pixel tile of
-                                  the GLOBAL frame, RMD_TILE_FLAGS_BYTES(width, height) bytes.  T marks
+                                  the GLOBAL frame, RMD_TILE_FLAGS_BYTES(width, height) bytes, 4-byte aligned.  T marks
                                   the tiles that contain short-history pixels, so V skips every other
                                   tile without reading a byte of it.  NULL = V visits all pixels.     */
 } rmd_svgf_frame_desc;
-#define RMD_TILE_FLAGS_BYTES(width, height) ((size_t)(((width) + 63) / 64) * (size_t)(((height) + 3) / 4))
+#define RMD_TILE_FLAGS_BYTES(width, height) (((size_t)(((width) + 63) / 64) * (size_t)(((height) + 3) / 4) + 3) / 4 * 4)
 
 /* Pass launchers.  [row0,row1) are GLOBAL output rows. */
 int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);

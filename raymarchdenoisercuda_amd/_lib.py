@@ -55,7 +55,7 @@ class SvgfParams(C.Structure):
                 ("var_h_threshold", C.c_int), ("var_radius", C.c_int),
                 ("sigma_n", C.c_float), ("sigma_z", C.c_float), ("sigma_l", C.c_float),
                 ("iterations", C.c_int), ("hist_iteration", C.c_int), ("atrous_variant", C.c_int),
-                ("reserved0", C.c_int), ("reserved1", C.c_int)]
+                ("tv_workgroups", C.c_int), ("reserved1", C.c_int)]
 
 
 class SvgfFrameDesc(C.Structure):

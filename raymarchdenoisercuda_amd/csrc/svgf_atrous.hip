@@ -148,23 +148,16 @@ __device__ __forceinline__ Center<f2> pack(const Center<float> a, const Center<f
     return k;
 }
 
-// Three packed forms the compiler does not pick by itself, spelled as VOP3P instructions.  `b` is the
-// (z, w) half of a staged float4; the values are exactly those of the generic C++ forms.
-//   - the [0,1] clamp as the clamp bit of the last packed fma of the cosine (the compiler only folds
-//     it into scalar v_fma_f32 and otherwise spends two v_max_f32 per pair);
-//   - broadcasting the HIGH half of b (the tap depth, .w) through op_sel instead of a v_mov_b32 first.
-//     (The same form for the variance accumulation costs registers the kernel does not have: 168
-//     VGPRs + scratch, so that one keeps its v_mov_b32.)
+// The [0,1] clamp of the cosine as the VOP3P clamp bit of its last packed fma: the compiler only folds
+// a clamp into scalar v_fma_f32 and otherwise spends two v_max_f32 per pair.  `b` is the (z, w) half of
+// a staged float4; same value as the generic form.  (Further hand-packed forms were tried and dropped:
+// the two differences z_p - z_t, l_p - l_t as v_pk_add_f32 save two issue slots per pair but no time
+// and cost 3 VGPRs, which moves the allocation from 152 to 160 registers and evicts the T wave that
+// otherwise fits beside three a-trous waves; a packed variance accumulation through op_sel spills.)
 __device__ __forceinline__ f2 pk_fma_lo_clamp(f2 a, f2 b, f2 c)        // clamp01(a * b.lo + c)
 {
     f2 r;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ f2 pk_sub_hi(f2 a, f2 b)                    // a - b.hi
-{
-    f2 r;
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 
@@ -180,29 +173,27 @@ __device__ __forceinline__ T tap_cosine(const Center<T>& k, const Tap& t)
 
 // One pixel's exponent, scalar on purpose: v_fma_f32 takes |.| and - as free source modifiers and
 // e0 as a literal (packed f32 has neither, and a packed e0 would need a VGPR pair per tap):
-//   e = e0 + sigma_n*log2(cos) - |dz|*iz - |dl|*il,   dz = z_p - z_t, dl = l_p - l_t
-// The differences themselves come in from the caller: for the (A,B) pair they are one v_pk_add_f32
-// each (negated broadcast tap value), read back here as the two halves of the result.
+//   e = e0 + sigma_n*log2(cos) - |z_p - z_t|*iz - |l_p - l_t|*il
 template <bool ZERO_AWARE>
-__device__ __forceinline__ float tap_exponent(float cosine, float e0, float sigma_n, float dz, float dl, float il,
-                                              const CenterAux& x, bool tap_zero, int adx, int ady)
+__device__ __forceinline__ float tap_exponent(float cosine, float e0, float sigma_n, float zp, float lp, float il,
+                                              const CenterAux& x, const Tap& t, bool tap_zero, int adx, int ady)
 {
     float e = fma_(sigma_n, log2_(cosine), e0);
     if (ZERO_AWARE) {   // Appendix A.A.2: both normals zero => w_n = 1, exactly one zero => 0
         if (x.zero) e = tap_zero ? e0 : kNegInf;
     }
-    if (adx | ady) e = fma_(-fabsf(dz), x.iz[len_class(adx, ady)], e);
-    return fma_(-fabsf(dl), il, e);
+    if (adx | ady) e = fma_(-fabsf(zp - t.n.w), x.iz[len_class(adx, ady)], e);
+    return fma_(-fabsf(lp - t.c.x), il, e);
 }
 
 template <class T>
-__device__ __forceinline__ void tap_accumulate(Acc<T>& s, T w, float lum, float r, float g, float var)
+__device__ __forceinline__ void tap_accumulate(Acc<T>& s, T w, const Tap& t)
 {
     s.sw += w;
-    s.sl = fma_(w, bc(lum, T{}), s.sl);
-    s.sr = fma_(w, bc(r, T{}), s.sr);
-    s.sg = fma_(w, bc(g, T{}), s.sg);
-    s.sv = fma_(w * w, bc(var, T{}), s.sv);
+    s.sl = fma_(w, bc(t.c.x, T{}), s.sl);
+    s.sr = fma_(w, bc(t.c.y, T{}), s.sr);
+    s.sg = fma_(w, bc(t.c.z, T{}), s.sg);
+    s.sv = fma_(w * w, bc(t.c.w, T{}), s.sv);
 }
 
 // one pixel, one tap
@@ -210,9 +201,9 @@ template <bool ZERO_AWARE>
 __device__ __forceinline__ void tap_single(Acc<float>& s, const Center<float>& k, const CenterAux& x, const Tap& t,
                                            float e0, int adx, int ady, float sigma_n)
 {
-    const float e = tap_exponent<ZERO_AWARE>(tap_cosine<float>(k, t), e0, sigma_n, k.z - t.n.w, k.lum - t.c.x, k.il, x,
+    const float e = tap_exponent<ZERO_AWARE>(tap_cosine<float>(k, t), e0, sigma_n, k.z, k.lum, k.il, x, t,
                                              ZERO_AWARE && is_zero3(t.n), adx, ady);
-    tap_accumulate<float>(s, exp2_(e), t.c.x, t.c.y, t.c.z, t.c.w);
+    tap_accumulate<float>(s, exp2_(e), t);
 }
 
 // the (A,B) pair sharing one tap: adyA / adyB are the tap's |row offset| seen from A and from B.
@@ -224,12 +215,11 @@ __device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const 
 {
     const f2 c = tap_cosine<f2>(k, t);
     const bool tz = ZERO_AWARE && is_zero3(t.n);
-    const f2 dz = pk_sub_hi(k.z, f2{ t.n.z, t.n.w }), dl = k.lum - bc(t.c.x, f2{});
-    float ca = c.x, cb = c.y, dza = dz.x, dzb = dz.y, dla = dl.x, dlb = dl.y;
-    asm("" : "+v"(ca), "+v"(cb), "+v"(dza), "+v"(dzb), "+v"(dla), "+v"(dlb));
-    const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, dza, dla, k.il.x, xa, tz, adx, adyA);
-    const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, dzb, dlb, k.il.y, xb, tz, adx, adyB);
-    tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t.c.x, t.c.y, t.c.z, t.c.w);
+    float ca = c.x, cb = c.y;
+    asm("" : "+v"(ca), "+v"(cb));
+    const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, k.z.x, k.lum.x, k.il.x, xa, t, tz, adx, adyA);
+    const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, k.z.y, k.lum.y, k.il.y, xb, t, tz, adx, adyB);
+    tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t);
 }
 
 // A.A.3.  c = the centre in (lum, r, g, var) form.

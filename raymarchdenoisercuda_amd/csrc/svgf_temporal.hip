@@ -29,15 +29,11 @@ struct TemporalArgs {
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 
-#ifndef RMD_T_MAXVGPR
-#define RMD_T_MAXVGPR 256     // experiment knob: cap T's VGPRs so its waves fit beside 3 a-trous waves per SIMD
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(RMD_T_MAXVGPR))) void svgf_temporal_kernel(TemporalArgs a)
+// One 64x4 tile of the GLOBAL tiling (rows 4k..4k+3, so T and V agree on tiles) by one workgroup.
+__device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int tile_x, const int tile_y)
 {
     const Geom g = a.g;
-    // workgroup = one 64x4 tile of the GLOBAL tiling (rows 4k..4k+3), so T and V agree on tiles
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int tile_y = a.row0 / 4 + blockIdx.y;
+    const int x = tile_x * 64 + (threadIdx.x & 63);
     const int y = tile_y * 4 + (threadIdx.x >> 6);
     bool short_history = false;
     if (x < g.W && y >= a.row0 && y < a.row1) {
@@ -137,8 +133,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(RMD_T_MAXVGPR))
     }
     if (a.tile_flags) {
         const int any = __syncthreads_or(short_history ? 1 : 0);
-        if (threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + blockIdx.x] = (unsigned char)(any != 0);
+        if (threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + tile_x] = (unsigned char)(any != 0);
     }
+}
+
+// one workgroup per tile: the pass on its own runs at HBM speed this way
+__global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
+{
+    temporal_tile(a, blockIdx.x, a.row0 / 4 + blockIdx.y);
+}
+
+// A fixed, small number of workgroups (one per CU) that walk over the tiles: the form that runs
+// UNDERNEATH the a-trous launches of the previous frame (rmd_svgf_params.tv_workgroups).  Three
+// a-trous workgroups leave 56 VGPRs per SIMD; one wave of this kernel fits there.  A grid of one
+// short workgroup per tile fits there too, but whenever an a-trous launch retires, its pending
+// workgroups refill the freed registers faster than the next a-trous launch can claim them, and
+// that launch then waits for the whole T pass (measured: 385 us instead of 135).  A persistent
+// grid has a constant footprint, so the next a-trous launch finds its three slots per CU.
+// EXPERIMENTAL and off by default: with 256 workgroups the pass takes 410 us on an idle GPU (one
+// wave per SIMD, ~3.3 us per tile of dependent gathers) and 565 us underneath a-trous launches,
+// which it slows from 130 to ~215 us each: together the two saturate HBM (3.5 + 2 TB/s) and the
+// a-trous ring refill stops being hidden.  Frames come out at 1.10 ms instead of 0.94 ms serial.
+__global__ __launch_bounds__(256) void svgf_temporal_persistent_kernel(TemporalArgs a, int tiles_y)
+{
+    // few instructions, long latencies: issue them ahead of the a-trous waves (which run at 3..0)
+    __builtin_amdgcn_s_setprio(3);
+    const int ntiles = a.tiles_x * tiles_y;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) temporal_tile(a, t % a.tiles_x, a.row0 / 4 + t / a.tiles_x);
 }
 
 }  // namespace rmd
@@ -157,6 +178,7 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
         return fail(RMD_E_NULL, "rmd_svgf_temporal: history planes must be all set or all NULL");
     if (row0 < 0 || row1 > f->height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_svgf_temporal: rows [%d,%d) invalid", row0, row1);
     if (p->max_motion_rows < 0 || p->h_max < 1) return fail(RMD_E_PARAM, "rmd_svgf_temporal: max_motion_rows/h_max invalid");
+    if (p->tv_workgroups < 0 || p->tv_workgroups > 65536) return fail(RMD_E_PARAM, "rmd_svgf_temporal: tv_workgroups %d outside [0,65536]", p->tv_workgroups);
     // current-frame planes: +1 row (depth gradient); history planes: +-(max_motion_rows) rows
     if (int e = check_rows_in_buffer(f, row0, row1 + 1, "rmd_svgf_temporal (current frame)")) return e;
     if (has_hist)
@@ -184,7 +206,11 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.alpha_color = p->alpha_color; a.alpha_moments = p->alpha_moments; a.k_z = p->k_z; a.k_n = p->k_n;
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
     dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
-    hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
+    if (p->tv_workgroups > 0) {
+        hipLaunchKernelGGL(svgf_temporal_persistent_kernel, dim3(p->tv_workgroups), dim3(256), 0, as_stream(stream), a, (int)grid.y);
+    } else {
+        hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
+    }
     RMD_LAUNCH_CHECK("svgf_temporal_kernel");
     return RMD_OK;
 }

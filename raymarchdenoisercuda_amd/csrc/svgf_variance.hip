@@ -25,22 +25,27 @@ struct VarianceArgs {
     float sigma_n, sigma_z;
 };
 
-__global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
+// RFIX > 0: the window radius as a compile-time constant, so the dy loop unrolls and the 2*(2R+1)
+// gathers of a window column are in flight together (the few waves that run the window in the
+// steady state are latency-bound).  RFIX = 0 keeps the generic loop for other radii.
+//
+// One pixel of tile (tile_x, tile_y) of the GLOBAL 64x4 tiling, the same tiles T flags.  Returns the
+// pixel's contribution to the frame statistics in s[4] (zeros for a pixel it does not visit).
+template <int RFIX>
+__device__ __forceinline__ void variance_pixel(const VarianceArgs& a, const int tile_x, const int tile_y, float (&s)[4])
 {
     const Geom g = a.g;
-    // workgroup = one 64x4 tile of the GLOBAL tiling, the same tiles T flags
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int tile_y = a.row0 / 4 + blockIdx.y;
+    const int x = tile_x * 64 + (threadIdx.x & 63);
     const int y = tile_y * 4 + (threadIdx.x >> 6);
-    if (a.tile_flags && a.tile_flags[(size_t)tile_y * a.tiles_x + blockIdx.x] == 0) return;   // whole tile: long history
     const bool active = x < g.W && y >= a.row0 && y < a.row1;
 
     float s_var = 0.0f, s_spatial = 0.0f, s_h = 0.0f, s_n = 0.0f;
+    s[0] = s[1] = s[2] = s[3] = 0.0f;
     if (active) {
         const size_t i = pix_index(g, x, y);
         const int h = (int)a.t_moments[i].z;
         const bool spatial = h < a.h_threshold;
-        if (!spatial && a.prefilled) return;       // (prefilled launches collect no statistics)
+        if (!spatial && a.prefilled) return;       // (prefilled launches collect no statistics; s stays 0)
         const float4 c = a.t_color[i];
         float4 o = c;
         if (spatial) {
@@ -50,35 +55,41 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
             const float za = a.sigma_z * fmaxf(gz, 1e-8f);
             const bool p_zero = is_zero3(nd);
             float sw = 0.0f, scx = 0.0f, scy = 0.0f, scz = 0.0f, sl = 0.0f, sl2 = 0.0f;
-            const int R = a.radius;
-            for (int dx = -R; dx <= R; ++dx) {
-                const int tx = x + dx;
-                if (tx < 0 || tx >= g.W) continue;
-                for (int dy = -R; dy <= R; ++dy) {
-                    const int ty = y + dy;
-                    if (ty < 0 || ty >= g.H) continue;
-                    const size_t ti = pix_index(g, tx, ty);
-                    const float4 tc = a.t_color[ti];
-                    const float4 tn = a.nd[ti];
-                    // log2-domain edge-stopping weight: w = exp2(sigma_n*log2(max(0,n.n)) - w_z*log2 e)
-                    float e;
-                    const bool t_zero = is_zero3(tn);
-                    if (p_zero || t_zero) {
-                        e = (p_zero && t_zero) ? 0.0f : kNegInf;
-                    } else {
-                        const float d = __builtin_fmaf(nd.z, tn.z, __builtin_fmaf(nd.y, tn.y, nd.x * tn.x));
-                        e = a.sigma_n * fast_log2(fmaxf(d, 0.0f));
-                    }
-                    if (dx != 0 || dy != 0) {
-                        const float len = sqrtf((float)(dx * dx + dy * dy));
-                        e = __builtin_fmaf(-fabsf(nd.w - tn.w), kLog2e / (za * len + 1e-8f), e);
-                    }
-                    const float w = fast_exp2(e);
-                    const float tl = lum3(tc.x, tc.y, tc.z);
-                    sw += w;
-                    scx = __builtin_fmaf(w, tc.x, scx); scy = __builtin_fmaf(w, tc.y, scy); scz = __builtin_fmaf(w, tc.z, scz);
-                    sl = __builtin_fmaf(w, tl, sl); sl2 = __builtin_fmaf(w, tl * tl, sl2);
+            auto tap = [&](const int dx, const int dy) {
+                const int tx = x + dx, ty = y + dy;
+                if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) return;
+                const size_t ti = pix_index(g, tx, ty);
+                const float4 tc = a.t_color[ti];
+                const float4 tn = a.nd[ti];
+                // log2-domain edge-stopping weight: w = exp2(sigma_n*log2(max(0,n.n)) - w_z*log2 e)
+                float e;
+                const bool t_zero = is_zero3(tn);
+                if (p_zero || t_zero) {
+                    e = (p_zero && t_zero) ? 0.0f : kNegInf;
+                } else {
+                    const float d = __builtin_fmaf(nd.z, tn.z, __builtin_fmaf(nd.y, tn.y, nd.x * tn.x));
+                    e = a.sigma_n * fast_log2(fmaxf(d, 0.0f));
                 }
+                if (dx != 0 || dy != 0) {
+                    const float len = sqrtf((float)(dx * dx + dy * dy));
+                    e = __builtin_fmaf(-fabsf(nd.w - tn.w), kLog2e / (za * len + 1e-8f), e);
+                }
+                const float w = fast_exp2(e);
+                const float tl = lum3(tc.x, tc.y, tc.z);
+                sw += w;
+                scx = __builtin_fmaf(w, tc.x, scx); scy = __builtin_fmaf(w, tc.y, scy); scz = __builtin_fmaf(w, tc.z, scz);
+                sl = __builtin_fmaf(w, tl, sl); sl2 = __builtin_fmaf(w, tl * tl, sl2);
+            };
+            // tap order dx outer / dy inner in both forms
+            if constexpr (RFIX > 0) {
+                for (int dx = -RFIX; dx <= RFIX; ++dx) {
+#pragma unroll
+                    for (int dy = -RFIX; dy <= RFIX; ++dy) tap(dx, dy);
+                }
+            } else {
+                const int R = a.radius;
+                for (int dx = -R; dx <= R; ++dx)
+                    for (int dy = -R; dy <= R; ++dy) tap(dx, dy);
             }
             if (!(sw < 1e-10f)) {
                 const float el = sl / sw, el2 = sl2 / sw;
@@ -92,6 +103,25 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
         a.v_color[i] = o;
         s_var = o.w; s_h = (float)h; s_n = 1.0f;
     }
+    s[0] = s_var; s[1] = s_spatial; s[2] = s_h; s[3] = s_n;
+}
+
+// one workgroup per tile
+template <int RFIX>
+__global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
+{
+    const int tile_y = a.row0 / 4 + blockIdx.y;
+    if (a.tile_flags) {
+        // whole tile long history: leave.  In the steady state that is ~98% of the 32k workgroups of a 4K
+        // frame, so the test is a SCALAR load of the aligned word holding the flag (uniform address),
+        // not a vector byte load: the launch is bound by how fast empty workgroups retire.
+        const size_t fi = (size_t)tile_y * a.tiles_x + blockIdx.x;
+        const unsigned word = reinterpret_cast<const unsigned*>(a.tile_flags)[fi >> 2];
+        if (((word >> (8u * (unsigned)(fi & 3))) & 0xffu) == 0u) return;
+    }
+    float s[4];
+    variance_pixel<RFIX>(a, blockIdx.x, tile_y, s);
+    float s_var = s[0], s_spatial = s[1], s_h = s[2], s_n = s[3];
     if (a.stats) {
         // wavefront __shfl reductions, then the 4 waves of the workgroup through LDS, then ONE
         // atomic per workgroup and statistic (520k same-address atomics per 4K frame, one per
@@ -104,6 +134,30 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
         if (threadIdx.x < 4) {
             const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
             if (part[0][3] + part[1][3] + part[2][3] + part[3][3] > 0.0f) atomicAdd(&a.stats[threadIdx.x], t);
+        }
+    }
+}
+
+// Fused frames only (tile flags from T, no statistics): a fixed number of workgroups, each looking
+// at the flags of every gridDim.x-th tile (64 per coalesced-by-stride load and ballot) and running
+// the flagged ones.  Constant footprint, for the same reason as svgf_temporal_persistent_kernel; the
+// stride spreads runs of flagged tiles (a disoccluded band along a frame edge) over the workgroups.
+template <int RFIX>
+__global__ __launch_bounds__(256) void svgf_variance_persistent_kernel(VarianceArgs a, int tiles_y)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int ntiles = a.tiles_x * tiles_y;
+    const int lane = threadIdx.x & 63;
+    const unsigned char* flags = a.tile_flags + (size_t)(a.row0 / 4) * a.tiles_x;
+    for (int base = 0; base < ntiles; base += 64 * (int)gridDim.x) {
+        const int t = base + lane * (int)gridDim.x + (int)blockIdx.x;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(t < ntiles && flags[t] != 0);    // the same in all four waves
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            const int tile = base + k * (int)gridDim.x + (int)blockIdx.x;
+            float s[4];
+            variance_pixel<RFIX>(a, tile % a.tiles_x, a.row0 / 4 + tile / a.tiles_x, s);
         }
     }
 }
@@ -125,6 +179,7 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     for (const void* q : planes16)
         if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_variance: float4 planes must be 16-byte aligned");
     if (f->t_color == f->v_color) return fail(RMD_E_BUFFER, "rmd_svgf_variance: t_color and v_color alias");
+    if (fused && f->v_tile_flags && !aligned_to(f->v_tile_flags, 4)) return fail(RMD_E_ALIGN, "rmd_svgf_variance: v_tile_flags must be 4-byte aligned");
 
     VarianceArgs a;
     a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
@@ -137,7 +192,15 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.tiles_x = (f->width + 63) / 64;
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z;
     dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
-    hipLaunchKernelGGL(svgf_variance_kernel, grid, dim3(256), 0, as_stream(stream), a);
+    if (p->tv_workgroups < 0 || p->tv_workgroups > 65536) return fail(RMD_E_PARAM, "rmd_svgf_variance: tv_workgroups %d outside [0,65536]", p->tv_workgroups);
+    if (a.tile_flags && p->tv_workgroups > 0) {
+        const dim3 pg(p->tv_workgroups);
+        if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_persistent_kernel<3>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
+        else               hipLaunchKernelGGL(svgf_variance_persistent_kernel<0>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
+    } else {
+        if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_kernel<3>, grid, dim3(256), 0, as_stream(stream), a);
+        else               hipLaunchKernelGGL(svgf_variance_kernel<0>, grid, dim3(256), 0, as_stream(stream), a);
+    }
     RMD_LAUNCH_CHECK("svgf_variance_kernel");
     return RMD_OK;
 }

@@ -5,6 +5,7 @@ torch supplies device memory (float32 CUDA tensors) and nothing else; every pass
 HIP kernels of librmd.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -42,7 +43,7 @@ def _ptr(t, name, rows, width, channels, dtype=torch.float32):
 
 def tile_flags_bytes(width, height):
     """RMD_TILE_FLAGS_BYTES of include/rmd_api.h."""
-    return ((width + 63) // 64) * ((height + 3) // 4)
+    return (((width + 63) // 64) * ((height + 3) // 4) + 3) // 4 * 4
 
 
 def frame_desc(width, height, buf_row0=0, buf_rows=None, ping=(None, None), stats=None, tile_flags=None,
@@ -156,12 +157,17 @@ class SvgfDenoiser:
         self.prev_nd = None
         self.pipelined = pipelined
         if pipelined:
-            self.stream_a = torch.cuda.Stream(device=device)      # a-trous iterations
-            self.stream_b = torch.cuda.Stream(device=device)      # T + V (+ the history halo exchange)
+            # The a-trous stream is the high-priority queue (measured: no effect on how the dispatcher
+            # arbitrates between T's pending workgroups and a new a-trous launch; kept as the intent).
+            self.stream_a = torch.cuda.Stream(device=device, priority=-1)       # a-trous iterations
+            self.stream_b = torch.cuda.Stream(device=device, priority=0)        # T + V (+ the history halo exchange)
             self._ev_hist, self._ev_tv = C.c_void_p(), C.c_void_p()
             check(lib.rmd_event_create(C.byref(self._ev_hist)))
             check(lib.rmd_event_create(C.byref(self._ev_tv)))
             self._hist_recorded = False
+            # Experiment knob: T and V as N persistent workgroups (rmd_svgf_params.tv_workgroups) while
+            # they run underneath a-trous launches.  Off by default: measured slower.
+            self._tv_workgroups = int(os.environ.get("RMD_TV_WORKGROUPS", "0"))
 
     def __del__(self):
         if getattr(self, "pipelined", False):
@@ -211,13 +217,16 @@ class SvgfDenoiser:
             frame(d, self.params, row0, row1, stream)
         else:
             sa, sb = self.stream_a, self.stream_b
+            self._params_tv = SvgfParams.from_buffer_copy(self.params)
+            if self._params_tv.tv_workgroups == 0:
+                self._params_tv.tv_workgroups = self._tv_workgroups
             sb.wait_stream(torch.cuda.current_stream())            # the caller's inputs
             if self._hist_recorded:                                # frame k's history complete (after its A_hist)
                 check(lib.rmd_stream_wait_event(sb.cuda_stream, self._ev_hist))
             with torch.cuda.stream(sb):
                 if before_tv is not None:
                     before_tv()
-                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(self.params), row0, row1, sb.cuda_stream))
+                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(self._params_tv), row0, row1, sb.cuda_stream))
             check(lib.rmd_event_record(self._ev_tv, sb.cuda_stream))
             check(lib.rmd_stream_wait_event(sa.cuda_stream, self._ev_tv))
             check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(self.params), row0, row1, sa.cuda_stream, self._ev_hist))

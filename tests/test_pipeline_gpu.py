@@ -36,6 +36,35 @@ def test_pipelined_frames_equal_serial_frames(rmd, cuda, width, height):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("workgroups", [1, 7, 256, 5000])
+def test_persistent_tv_grids_equal_one_workgroup_per_tile(rmd, cuda, workgroups):
+    """rmd_svgf_params.tv_workgroups: T and V as N persistent workgroups walking the tiles give the
+    bits of the one-workgroup-per-tile launch, for whole frames and for a row range (strip)."""
+    width, height = 333, 150
+    p0 = rmd.default_params()
+    p0.max_motion_rows = 8
+    p1 = rmd.SvgfParams.from_buffer_copy(p0)
+    p1.tv_workgroups = workgroups
+    for rows in (None, (37, 101)):
+        dens = [rmd.SvgfDenoiser(width, height, params=p, debug=True) for p in (p0, p1)]
+        for f in range(4):
+            c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
+            outs = []
+            for den in dens:
+                out = torch.zeros_like(c)
+                if rows is None:
+                    den.denoise(c, nd, m, out)
+                else:
+                    den.denoise(c, nd, m, out, row0=rows[0], row1=rows[1])
+                outs.append(out)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1]), f"frame {f} rows {rows}"
+            assert torch.equal(dens[0].t_debug, dens[1].t_debug)
+            assert torch.equal(dens[0].tile_flags, dens[1].tile_flags)
+            for a, b in zip(dens[0].history(), dens[1].history()):
+                assert torch.equal(a, b)
+
+
 def test_pipelined_repeatable(rmd, cuda):
     """Race check: many frames, several runs, always the same bits."""
     p = rmd.default_params()
