@@ -53,6 +53,9 @@ for it in range(5):
         if sel.any():
             d = dur[sel] / 100.0
             print(f"    {name:8s} n={sel.sum():4d} duration us: min {d.min():.1f}  p50 {np.percentile(d, 50):.1f}  p90 {np.percentile(d, 90):.1f}  max {d.max():.1f}")
+    print("    per-XCD end us (p50/max): " + "  ".join(f"{np.percentile(end[xcc == k], 50) / 100:.0f}/{end[xcc == k].max() / 100:.0f}" for k in range(8)))
+    cu_end = np.array([end[cu_key == k].max() for k in np.unique(cu_key)]) / 100.0
+    print(f"    per-CU last end us: p10 {np.percentile(cu_end, 10):.1f}  p50 {np.percentile(cu_end, 50):.1f}  p90 {np.percentile(cu_end, 90):.1f}  max {cu_end.max():.1f}")
     late = start > np.percentile(end, 10)
     print(f"    workgroups that start after the first 10% have ended: {late.sum()}")
     occ = (dur.sum() / max(end.max(), 1)) / (len(per_cu) * 3)
