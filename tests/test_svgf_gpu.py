@@ -203,6 +203,39 @@ def test_full_frame_sequence_vs_oracle_and_golden(rmd, orc, cuda):
         close(hm, fr.t_moments, TOL_FRAME, f"frame {f} hist_moments")
 
 
+NON_DEFAULT = [
+    dict(sigma_n=32.0, sigma_z=0.5, sigma_l=10.0, iterations=3, hist_iteration=1, var_radius=2, alpha_color=0.2, alpha_moments=0.5),
+    dict(sigma_n=1.0, sigma_z=4.0, sigma_l=1.0, iterations=1, hist_iteration=0, var_radius=1, var_h_threshold=2, h_max=4, k_n=0.5, k_z=2.0),
+    dict(sigma_n=256.0, sigma_z=0.25, sigma_l=0.5, iterations=6, hist_iteration=5, var_radius=4, var_h_threshold=8, max_motion_rows=2),
+    # alpha_color = 1: no colour accumulation.  (alpha_moments = 1 or var_radius = 0 would make every
+    # variance exactly 0; the luminance weight exp(-|dl| / (sigma_l*0 + 1e-8)) is then a step function of
+    # rounding errors and no two implementations agree -- an ill-conditioned setting, not a parity case.)
+    dict(iterations=4, hist_iteration=3, var_radius=1, alpha_color=1.0, alpha_moments=0.6),
+]
+
+
+@pytest.mark.parametrize("over", NON_DEFAULT)
+def test_full_frames_with_non_default_parameters(rmd, orc, cuda, over):
+    """Every rmd_svgf_params field away from its default (other sigma, fewer / more iterations incl. a
+    6th one on the direct kernel, history taken from a later or the last iteration, other V windows
+    through the generic-radius kernel, alpha = 1 i.e. no accumulation): 4 frames against the oracle."""
+    width, height = 150, 90
+    p = orc.default_params()
+    for k, v in over.items():
+        assert hasattr(p, k)
+        setattr(p, k, v)
+    ref = oracle_sequence(orc, width, height, 4, p)
+    den = rmd.SvgfDenoiser(width, height, params=p, debug=True)
+    for f, fr in enumerate(ref):
+        out = den.denoise(dev(fr.color), dev(fr.nd), dev(fr.motion))
+        torch.cuda.synchronize()
+        assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}: integer outputs"
+        close(out, fr.out_color, TOL_FRAME, f"frame {f} out_color {over}")
+        hc, hm = den.history()
+        close(hc, fr.hist_color_out, TOL_FRAME, f"frame {f} hist_color {over}")
+        close(hm, fr.t_moments, TOL_FRAME, f"frame {f} hist_moments {over}")
+
+
 def test_cornell_full_svgf(rmd, orc, cuda):
     """BASELINE config 2 input (Cornell planes as float G-buffer), 2 static frames, full frame 500x500."""
     color, nd, motion = orc.cornell_svgf_inputs()
