@@ -79,18 +79,24 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps):
     achieved = ATROUS_BYTES_PER_PX * px / (avg_ms * 1e-3) / 1e9
     # PMC-measured HBM bytes per launch, if a rocprofv3 --pmc pass of this command was reduced
     # into profiles/ (tools/pmc_traffic.py); null otherwise.
-    traffic = None
+    traffic, valu = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("atrous_hbm_bytes_per_launch")
+            pmc = json.load(open(tpath))
+            traffic = pmc.get("atrous_hbm_bytes_per_launch")
+            vi = pmc.get("valu_issue")
+            if vi:   # the bound the kernel actually sits on (PMC passes of the same kernels, tools/pmc_passes.sh)
+                valu = {"busy_frac": vi["avg_valu_busy_frac"], "resident_waves_per_simd": vi["avg_resident_waves_per_simd"],
+                        "max_waves_per_simd": 3, "source": "profiles/pmc_traffic.json (rocprofv3 --pmc)"}
         except Exception:
-            traffic = None
+            traffic, valu = None, None
     return {
         "bound": "hbm", "kernel": "atrous_stream_kernel<S,2> (one a-trous iteration, avg over S=1,2,4,8,16)",
         "note": "priced against HBM as BASELINE.json asks; the kernel is VALU-issue bound (DESIGN.md §4)",
         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
+        "valu_issue": valu,
         "algorithmic_bytes_per_launch": ATROUS_BYTES_PER_PX * px,
         "avg_launch_ms": round(avg_ms, 5),
         "per_iteration_ms": [round(v, 5) for v in per_iter],
