@@ -127,6 +127,196 @@ __global__ __launch_bounds__(256) void box_lds_kernel(const uchar4* __restrict__
     }
 }
 
+// ---- stream kernel: the fast path for radius 1..4 (the reference runs radius 2) ---------------
+// No LDS, no barriers.  A wave owns a 256-pixel column strip of one band of rows (a lane = 4
+// consecutive pixels = one 16-byte load, 1 KB per wave and row) and walks down it:
+//   - the pixels left / right of a lane's four come from the neighbouring lanes through DPP
+//     wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1); lanes 0 and 63 load the strip's
+//     4-pixel halo themselves and feed it in as the shift's `old` operand;
+//   - channels are carried as packed 16-bit sums, (R | B<<16) and G: a horizontal sum is
+//     <= 9*255 and a window sum <= 81*255 = 20655, so halves never carry into each other;
+//   - the vertical sum is a running one over a ring of the last 2R+1 row sums held in registers
+//     (the row loop is unrolled by the ring length, all indices static);
+//   - rows are prefetched one ring length ahead (5 x 1 KB per wave in flight at radius 2);
+//   - interior pixels divide by the constant (2R+1)^2 with one v_mul_hi_u32 (Granlund-Montgomery
+//     magic number, exact for every sum < 2^16: checked on the host before the launch); pixels
+//     whose window leaves the frame use the reference's float division.  Both equal
+//     (unsigned char)((float)sum / (float)count): the quotient of two integers < 2^24 whose
+//     fractional part is >= 1/count away from the next integer cannot be rounded across it.
+// Algorithmic traffic 8 B/px; the pass is HBM-bound (66 MB at 4K).
+__device__ __forceinline__ unsigned dpp_from_left(unsigned old, unsigned src)      // lane i <- lane i-1, lane 0 keeps old
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned dpp_from_right(unsigned old, unsigned src)     // lane i <- lane i+1, lane 63 keeps old
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x130, 0xf, 0xf, false);
+}
+
+template <int R, bool GRAY>
+__global__ __launch_bounds__(256) void box_stream_kernel(const uint4* __restrict__ in, uint4* __restrict__ out,
+                                                         int W, int H, int nstrips, int band_rows, unsigned magic)
+{
+    constexpr int K = 2 * R + 1;                 // ring length = window height
+    constexpr int U = K == 3 ? 6 : K;            // unroll / prefetch depth, a multiple of K
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = gw % nstrips, band = gw / nstrips;
+    const int yb = band * band_rows;
+    if (yb >= H) return;
+    const int ye = min(H, yb + band_rows);
+    const int x0 = strip * 256, x = x0 + lane * 4;
+    const bool xin = x < W;                      // W % 4 == 0: a lane's four pixels are all in or all out
+    const int W4 = W >> 2;
+    // halo pixels of the strip: lane 0 fetches [x0-4, x0), lane 63 fetches [x0+256, x0+260)
+    const bool hact = (lane == 0 && x0 > 0) || (lane == 63 && x0 + 256 < W);
+    const int hx4 = lane == 0 ? (x0 >> 2) - 1 : (x0 >> 2) + 64;
+
+    uint4 pre[U], preh[U];
+    auto fetch = [&](const int y, uint4& own, uint4& halo) {
+        own = make_uint4(0u, 0u, 0u, 0u);
+        halo = own;
+        if (y >= 0 && y < H) {                   // wave-uniform
+            const size_t row = (size_t)y * (size_t)W4;
+            if (xin) own = in[row + (size_t)(x >> 2)];
+            if (hact) halo = in[row + (size_t)hx4];
+        }
+    };
+    const int yfirst = yb - R, ylast = ye + R;   // input rows [yfirst, ylast)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        pre[u] = make_uint4(0u, 0u, 0u, 0u); preh[u] = pre[u];
+        if (yfirst + u < ylast) fetch(yfirst + u, pre[u], preh[u]);
+    }
+
+    unsigned ring_rb[K][4], ring_g[K][4], v_rb[4], v_g[4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ring_rb[k][i] = 0u; ring_g[k][i] = 0u; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v_rb[i] = 0u; v_g[i] = 0u; }
+
+    const bool lane_interior = x - R >= 0 && x + 3 + R < W;
+    for (int base = yfirst; base < ylast; base += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int y = base + u;
+            if (y >= ylast) break;               // wave-uniform
+            const uint4 own = pre[u], halo = preh[u];
+            if (y + U < ylast) fetch(y + U, pre[u], preh[u]);     // wave-uniform
+            // ---- packed words of the 4 + 2R pixels this lane's sums touch: index j <-> pixel x - R + j
+            unsigned rb[4 + 2 * R], g[4 + 2 * R];
+            const unsigned o[4] = { own.x, own.y, own.z, own.w }, hh[4] = { halo.x, halo.y, halo.z, halo.w };
+            unsigned orb[4], og[4], hrb[4], hg[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                orb[i] = GRAY ? (o[i] & 0xffu) : (o[i] & 0x00ff00ffu);  og[i] = (o[i] >> 8) & 0xffu;
+                hrb[i] = GRAY ? (hh[i] & 0xffu) : (hh[i] & 0x00ff00ffu); hg[i] = (hh[i] >> 8) & 0xffu;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { rb[R + i] = orb[i]; g[R + i] = og[i]; }
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                // pixel x-1-j = the left neighbour's pixel 3-j; pixel x+4+j = the right neighbour's pixel j
+                rb[R - 1 - j] = dpp_from_left(hrb[3 - j], orb[3 - j]);
+                rb[R + 4 + j] = dpp_from_right(hrb[j], orb[j]);
+                if (!GRAY) {
+                    g[R - 1 - j] = dpp_from_left(hg[3 - j], og[3 - j]);
+                    g[R + 4 + j] = dpp_from_right(hg[j], og[j]);
+                }
+            }
+            // ---- horizontal sums of the four pixels (sliding), then the vertical running sum
+            unsigned h_rb[4], h_g[4];
+            h_rb[0] = rb[0]; h_g[0] = GRAY ? 0u : g[0];
+#pragma unroll
+            for (int j = 1; j < K; ++j) { h_rb[0] += rb[j]; if (!GRAY) h_g[0] += g[j]; }
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                h_rb[i] = h_rb[i - 1] + rb[i + K - 1] - rb[i - 1];
+                h_g[i] = GRAY ? 0u : h_g[i - 1] + g[i + K - 1] - g[i - 1];
+            }
+            constexpr int slot_of_u[6] = { 0 % K, 1 % K, 2 % K, 3 % K, 4 % K, 5 % K };
+            const int slot = U == K ? u : slot_of_u[u < 6 ? u : 0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v_rb[i] += h_rb[i] - ring_rb[slot][i]; ring_rb[slot][i] = h_rb[i];
+                if (!GRAY) { v_g[i] += h_g[i] - ring_g[slot][i]; ring_g[slot][i] = h_g[i]; }
+            }
+            // ---- output row y - R
+            const int yo = y - R;
+            if (yo < yb || yo >= ye) continue;   // wave-uniform
+            const bool row_interior = yo - R >= 0 && yo + R < H;
+            unsigned res[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned sr = v_rb[i] & 0xffffu, sb = v_rb[i] >> 16, sg = v_g[i];
+                const unsigned qr = __umulhi(sr, magic);
+                if (GRAY) res[i] = qr * 0x010101u;
+                else      res[i] = qr | (__umulhi(sg, magic) << 8) | (__umulhi(sb, magic) << 16);
+            }
+            if (!(row_interior && lane_interior)) {
+                // a window that leaves the frame: count the in-bounds taps, divide as the reference does
+                const int cnty = min(yo + R, H - 1) - max(yo - R, 0) + 1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int px = x + i;
+                    const int cntx = min(px + R, W - 1) - max(px - R, 0) + 1;
+                    const float norm = (float)(cntx * cnty);
+                    const unsigned sr = v_rb[i] & 0xffffu, sb = v_rb[i] >> 16, sg = v_g[i];
+                    const unsigned qr = (unsigned)(unsigned char)((float)sr / norm);
+                    if (GRAY) res[i] = qr * 0x010101u;
+                    else      res[i] = qr | ((unsigned)(unsigned char)((float)sg / norm) << 8) | ((unsigned)(unsigned char)((float)sb / norm) << 16);
+                }
+            }
+            if (xin) out[(size_t)yo * (size_t)W4 + (size_t)(x >> 2)] = make_uint4(res[0], res[1], res[2], res[3]);
+        }
+    }
+}
+
+// magic number M with floor(s / n) == __umulhi(s, M) for every s < 2^16 (Granlund & Montgomery);
+// verified exhaustively for the sums that can occur, 0 = no such number found
+static unsigned box_magic(int n)
+{
+    int L = 0;
+    while ((1 << L) < n) ++L;
+    if (L < 1) return 0u;
+    const unsigned long long m = ((1ull << (16 + L)) / (unsigned)n + 1ull) << (16 - L);
+    if (m >> 32) return 0u;
+    for (unsigned s = 0; s <= 255u * (unsigned)n; ++s)
+        if ((unsigned)(((unsigned long long)s * m) >> 32) != s / (unsigned)n) return 0u;
+    return (unsigned)m;
+}
+
+template <bool GRAY>
+static bool launch_box_stream(const uchar4* in, uchar4* out, int W, int H, int radius, hipStream_t stream)
+{
+    static const bool disabled = getenv("RMD_BOX_STREAM") && atoi(getenv("RMD_BOX_STREAM")) == 0;    // A/B knob
+    if (disabled || radius < 1 || radius > 4 || (W & 3) || !aligned_to(in, 16) || !aligned_to(out, 16)) return false;
+    const unsigned magic = box_magic((2 * radius + 1) * (2 * radius + 1));
+    if (!magic) return false;
+    const int nstrips = (W + 255) / 256;
+    // Band height: the pass is latency-bound until the chip holds ~4 waves per SIMD, so aim for ~4096
+    // waves (8 rows at 4K, 32 at 8K; measured at 4K: 8 rows 20.7 us, 16 rows 23.6, 32 rows 33.8) and
+    // accept that a band re-reads the 2R halo rows its neighbours fetch too (served by L2 / Infinity Cache).
+    static const int band_env = getenv("RMD_BOX_BAND") ? atoi(getenv("RMD_BOX_BAND")) : 0;                // tuning knob
+    int band_rows = (int)(((long long)H * nstrips + 4095) / 4096);
+    band_rows = band_rows < 8 ? 8 : (band_rows > 64 ? 64 : (band_rows + 3) / 4 * 4);
+    if (band_env > 0) band_rows = band_env;
+    const int nbands = (H + band_rows - 1) / band_rows;
+    const int waves = nstrips * nbands;
+    const dim3 grid((waves + 3) / 4);
+    const uint4* in4 = reinterpret_cast<const uint4*>(in);
+    uint4* out4 = reinterpret_cast<uint4*>(out);
+    switch (radius) {
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(box_stream_kernel<1, GRAY>), grid, dim3(256), 0, stream, in4, out4, W, H, nstrips, band_rows, magic); break;
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(box_stream_kernel<2, GRAY>), grid, dim3(256), 0, stream, in4, out4, W, H, nstrips, band_rows, magic); break;
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(box_stream_kernel<3, GRAY>), grid, dim3(256), 0, stream, in4, out4, W, H, nstrips, band_rows, magic); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(box_stream_kernel<4, GRAY>), grid, dim3(256), 0, stream, in4, out4, W, H, nstrips, band_rows, magic); break;
+    }
+    return true;
+}
+
 static size_t box_lds_bytes(int radius)
 {
     const size_t tileW = kBoxBlockX + 2 * radius, tileH = kTileY + 2 * radius;
@@ -155,7 +345,9 @@ static int run_levels(const rmd_gbuffer& f, const rmd_filter_params& p, bool use
     for (int level = 0; level < p.depth; ++level) {
         const uchar4* in = reinterpret_cast<const uchar4*>(level == 0 ? f.render : f.buffer[level % 2]);
         uchar4* out = reinterpret_cast<uchar4*>(level == p.depth - 1 ? f.denoised : f.buffer[(level + 1) % 2]);
-        if (use_lds) {
+        if (launch_box_stream<GRAY>(in, out, W, H, p.radius, stream)) {
+            // radius 1..4 on 16-byte aligned planes of a width that is a multiple of 4: the stream kernel
+        } else if (use_lds) {
             dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + kTileY - 1) / kTileY);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(box_lds_kernel<GRAY>), grid, dim3(256), box_lds_bytes(p.radius), stream,
                                in, out, W, H, p.radius);

@@ -45,6 +45,22 @@ def test_edge_shapes(rmd, orc, cuda, shape, r, tiled, cache):
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("r", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(1, 4), (3, 8), (20, 252), (33, 256), (40, 260), (75, 512), (130, 1028), (7, 2052)])
+def test_stream_kernel_radii_and_ragged_strips(rmd, orc, cuda, shape, r):
+    """The radius 1..4 fast path (widths that are multiples of 4: 256-pixel strips walked by one wave,
+    neighbours through DPP wave shifts, strip halos from lanes 0 / 63, 16-row bands with a register
+    ring): one strip, strips that end in the middle of a wave, a last strip of a single lane, frames
+    shorter than the window and than a band; RGB (tiled) and gray-from-R (baseline), bit-exact."""
+    rng = np.random.default_rng(100 * r + shape[1])
+    img = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
+    img[rng.integers(0, shape[0]), :, :] = 255                     # a saturated row: the largest sums
+    for tiled in (True, False):
+        got = run_gpu(rmd, img, r, 1, tiled, True)
+        want = orc.box_filter(img, r, 1, gray_from_r=not tiled)
+        assert (got == want).all(), (shape, r, tiled, np.argwhere(got != want)[:4])
+
+
 @pytest.mark.parametrize("tiled", [False, True])
 def test_multi_level_ping_pong(rmd, orc, cuda, tiled):
     """depth>1 with the reference's plane routing (src/filter.cu:24-25), one launch per level."""
