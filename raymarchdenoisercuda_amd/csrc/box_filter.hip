@@ -160,7 +160,9 @@ __global__ __launch_bounds__(256) void box_stream_kernel(const uint4* __restrict
     constexpr int K = 2 * R + 1;                 // ring length = window height
     constexpr int U = K == 3 ? 6 : K;            // unroll / prefetch depth, a multiple of K
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave index is the same in every lane: say so, and strip / band / every row number and
+    // row test below stays in SGPRs (s_cmp + s_cbranch instead of v_cmp + exec masking)
+    const int gw = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int strip = gw % nstrips, band = gw / nstrips;
     const int yb = band * band_rows;
     if (yb >= H) return;
@@ -170,24 +172,21 @@ __global__ __launch_bounds__(256) void box_stream_kernel(const uint4* __restrict
     const int W4 = W >> 2;
     // halo pixels of the strip: lane 0 fetches [x0-4, x0), lane 63 fetches [x0+256, x0+260)
     const bool hact = (lane == 0 && x0 > 0) || (lane == 63 && x0 + 256 < W);
-    const int hx4 = lane == 0 ? (x0 >> 2) - 1 : (x0 >> 2) + 64;
-
+    // Loads are UNCONDITIONAL (addresses clamped into the plane, values masked to 0 afterwards): with
+    // loads inside branches the compiler cannot count them and drains the whole prefetch queue
+    // (s_waitcnt vmcnt(0)) at every trip of the row loop.
+    const int xc4 = min(x >> 2, W4 - 1);
+    const int hc4 = min(max(lane == 0 ? (x0 >> 2) - 1 : (x0 >> 2) + 64, 0), W4 - 1);
+    const unsigned own_mask = xin ? 0xffffffffu : 0u, halo_mask = hact ? 0xffffffffu : 0u;
+    const int yfirst = yb - R, ylast = ye + R;   // input rows [yfirst, ylast)
     uint4 pre[U], preh[U];
     auto fetch = [&](const int y, uint4& own, uint4& halo) {
-        own = make_uint4(0u, 0u, 0u, 0u);
-        halo = own;
-        if (y >= 0 && y < H) {                   // wave-uniform
-            const size_t row = (size_t)y * (size_t)W4;
-            if (xin) own = in[row + (size_t)(x >> 2)];
-            if (hact) halo = in[row + (size_t)hx4];
-        }
+        const size_t row = (size_t)min(max(y, 0), H - 1) * (size_t)W4;
+        own = in[row + (size_t)xc4];
+        halo = in[row + (size_t)hc4];
     };
-    const int yfirst = yb - R, ylast = ye + R;   // input rows [yfirst, ylast)
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        pre[u] = make_uint4(0u, 0u, 0u, 0u); preh[u] = pre[u];
-        if (yfirst + u < ylast) fetch(yfirst + u, pre[u], preh[u]);
-    }
+    for (int u = 0; u < U; ++u) fetch(yfirst + u, pre[u], preh[u]);
 
     unsigned ring_rb[K][4], ring_g[K][4], v_rb[4], v_g[4];
 #pragma unroll
@@ -201,13 +200,14 @@ __global__ __launch_bounds__(256) void box_stream_kernel(const uint4* __restrict
     for (int base = yfirst; base < ylast; base += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int y = base + u;
-            if (y >= ylast) break;               // wave-uniform
+            const int y = base + u;               // (rows >= ylast of the last trip are computed and dropped)
             const uint4 own = pre[u], halo = preh[u];
-            if (y + U < ylast) fetch(y + U, pre[u], preh[u]);     // wave-uniform
+            const unsigned row_mask = (y >= 0 && y < H) ? 0xffffffffu : 0u;      // wave-uniform
+            const unsigned om = own_mask & row_mask, hm = halo_mask & row_mask;
             // ---- packed words of the 4 + 2R pixels this lane's sums touch: index j <-> pixel x - R + j
             unsigned rb[4 + 2 * R], g[4 + 2 * R];
-            const unsigned o[4] = { own.x, own.y, own.z, own.w }, hh[4] = { halo.x, halo.y, halo.z, halo.w };
+            const unsigned o[4] = { own.x & om, own.y & om, own.z & om, own.w & om };
+            const unsigned hh[4] = { halo.x & hm, halo.y & hm, halo.z & hm, halo.w & hm };
             unsigned orb[4], og[4], hrb[4], hg[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -243,6 +243,10 @@ __global__ __launch_bounds__(256) void box_stream_kernel(const uint4* __restrict
                 v_rb[i] += h_rb[i] - ring_rb[slot][i]; ring_rb[slot][i] = h_rb[i];
                 if (!GRAY) { v_g[i] += h_g[i] - ring_g[slot][i]; ring_g[slot][i] = h_g[i]; }
             }
+            // ---- refill this row's prefetch slot IN PLACE, now that its old contents are consumed (issued
+            // before they are, the load needs other registers and the compiler rotates the slots with
+            // copies at the loop end, which also have to wait for every load in flight)
+            fetch(y + U, pre[u], preh[u]);
             // ---- output row y - R
             const int yo = y - R;
             if (yo < yb || yo >= ye) continue;   // wave-uniform
@@ -297,11 +301,14 @@ static bool launch_box_stream(const uchar4* in, uchar4* out, int W, int H, int r
     if (!magic) return false;
     const int nstrips = (W + 255) / 256;
     // Band height: the pass is latency-bound until the chip holds ~4 waves per SIMD, so aim for ~4096
-    // waves (8 rows at 4K, 32 at 8K; measured at 4K: 8 rows 20.7 us, 16 rows 23.6, 32 rows 33.8) and
+    // waves (11 rows at 4K, 36 at 8K; measured at 4K: 6 rows 23.1 us, 11 rows 18.4, 16 rows 19.4) and
     // accept that a band re-reads the 2R halo rows its neighbours fetch too (served by L2 / Infinity Cache).
     static const int band_env = getenv("RMD_BOX_BAND") ? atoi(getenv("RMD_BOX_BAND")) : 0;                // tuning knob
     int band_rows = (int)(((long long)H * nstrips + 4095) / 4096);
-    band_rows = band_rows < 8 ? 8 : (band_rows > 64 ? 64 : (band_rows + 3) / 4 * 4);
+    band_rows = band_rows < 8 ? 8 : (band_rows > 64 ? 64 : band_rows);
+    // the row loop runs in whole trips of U rows: make band + 2R a multiple of U (11 rows at 4K, radius 2)
+    const int trip = (2 * radius + 1) == 3 ? 6 : 2 * radius + 1;
+    band_rows = (band_rows + 2 * radius + trip - 1) / trip * trip - 2 * radius;
     if (band_env > 0) band_rows = band_env;
     const int nbands = (H + band_rows - 1) / band_rows;
     const int waves = nstrips * nbands;
