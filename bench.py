@@ -276,7 +276,9 @@ def main():
         # the other frame sizes north_star names, same pipeline, short runs (not the headline value)
         del frames, sd
         torch.cuda.empty_cache()
-        result["other_sizes"] = {f"{w}x{h}": other_size(rmd, torch, w, h, p) for w, h in ((1920, 1080), (7680, 4320))}
+        # (1080p frames are 0.3 ms: more of them for a stable figure; 8K G-buffers are 1.3 GB per frame)
+        result["other_sizes"] = {f"{w}x{h}": other_size(rmd, torch, w, h, p, frames=n, warm=wu)
+                                 for w, h, n, wu in ((1920, 1080, 48, 8), (7680, 4320, 16, 4))}
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
