@@ -270,6 +270,35 @@ def test_cornell_tiled_to_1080p(rmd, orc, cuda):
     assert (ref[1].t_debug[..., 3] == 2).mean() > 0.5 and (ref[1].t_debug[..., 3] == 1).any()
 
 
+def test_cornell_4k_animated_sequence(rmd, orc, cuda):
+    """BASELINE config 5 in miniature: the Cornell planes tiled to 3840x2160, an analytic camera pan
+    (quarter-pixel multiples, so reprojection positions are exact) and per-frame re-seeded noise on the
+    radiance; 4 frames of full SVGF against the oracle, integer outputs bit-exact."""
+    color0, nd0, _ = orc.cornell_svgf_inputs()
+    tile = lambda a: np.ascontiguousarray(np.tile(a, (5, 8, 1))[:2160, :3840])  # noqa: E731
+    base, nd = tile(color0), tile(nd0)
+    motion = np.zeros((2160, 3840, 2), np.float32)
+    motion[..., 0], motion[..., 1] = 0.75, 0.25
+    p = orc.default_params()
+    p.max_motion_rows = 8
+    rng = np.random.default_rng(2024)
+    frames = []
+    for f in range(4):
+        noise = 1.0 + 0.5 * (rng.random(base.shape[:2], dtype=np.float32) - 0.5)
+        c = base.copy()
+        c[..., :3] *= noise[..., None]
+        frames.append((c, nd, motion))
+    ref = oracle_sequence(orc, 3840, 2160, 4, p, inputs=frames)
+    den = rmd.SvgfDenoiser(3840, 2160, params=p, debug=True)
+    for f, fr in enumerate(ref):
+        out = den.denoise(dev(frames[f][0]), dev(nd), dev(motion))
+        torch.cuda.synchronize()
+        assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}: integer outputs"
+        close(out, fr.out_color, TOL_FRAME, f"cornell 4K frame {f}")
+    h = ref[3].t_debug[..., 3]
+    assert (h == 4).mean() > 0.9                                       # history accumulates under the pan
+
+
 def test_c_context_matches_python_denoiser(rmd, cuda):
     """rmd_svgf_context_* (the C-side owner of the history planes) gives the same frames."""
     import ctypes as C
