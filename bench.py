@@ -122,6 +122,31 @@ def other_size(rmd, torch, width, height, p, frames=16, warm=4):
             "effective_GBps": round(FULL_BYTES_PER_PX * width * height * frames / dt / 1e9, 1), "frames": frames}
 
 
+def reference_api_kernels(rmd, torch, width=3840, height=2160):
+    """The reference's own entry points (uchar4 box mean, radius 2, depth 1: src/test.cu:68-90) on a 4K
+    plane: microseconds per launch and algorithmic GB/s (8 B/px).  Not the headline value."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    render = torch.randint(0, 256, (height, width, 4), dtype=torch.uint8, device="cuda", generator=g)
+    out = torch.empty_like(render)
+    frame = rmd.make_gbuffer(render, out)
+    p = rmd.FilterParams(radius=2, depth=1)
+    res = {}
+    for name, fn in (("filterKernelBaseline", rmd.filterKernelBaseline), ("filterKernelTiled", rmd.filterKernelTiled)):
+        for _ in range(3):
+            fn(frame, p)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn(frame, p)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        res[name] = {"us_per_launch": round(us, 1), "GBps_algorithmic": round(8.0 * width * height / us / 1e3, 1)}
+    res["workload"] = f"{width}x{height} uchar4, FilterParams{{AVERAGE, radius 2, depth 1}}"
+    return res
+
+
 def usable_cores(hardware_threads):
     """Host threads this process may actually run at once: affinity mask and cgroup CPU quota (the
     one-GPU boxes of this pool expose 256 hardware threads behind a 16-CPU quota; 256 oracle threads
@@ -279,6 +304,7 @@ def main():
         # (1080p frames are 0.3 ms: more of them for a stable figure; 8K G-buffers are 1.3 GB per frame)
         result["other_sizes"] = {f"{w}x{h}": other_size(rmd, torch, w, h, p, frames=n, warm=wu)
                                  for w, h, n, wu in ((1920, 1080, 48, 8), (7680, 4320, 16, 4))}
+        result["reference_api"] = reference_api_kernels(rmd, torch)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
