@@ -60,7 +60,7 @@ struct AtrousArgs {
     int step;
     float sigma_n, sigma_z, sigma_l;
     // stream variant work decomposition
-    int band_h, nstrips, nblocks, per_xcd;
+    int band_h, band_base, nstrips, nblocks, per_xcd;
 };
 
 // log2 of the B3-spline taps {3/8, 1/4, 1/16} (reference src/filter.cu:10)
@@ -645,8 +645,9 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(A
     const int r = L % S, t = L / S;
     const int strip = t % a.nstrips, band = t / a.nstrips;
     const int x0 = strip * C::CW;
-    // bands are aligned to multiples of band_h (a multiple of 2S*NP) in GLOBAL rows
-    const int yb = (a.row0 / a.band_h + band) * a.band_h;
+    // bands start at band_base + k*band_h; band_base is row0 rounded down to a multiple of 2S, which is
+    // all the (A,B) pairing needs (global lattice index floor(y/S) even at the top of a band)
+    const int yb = a.band_base + band * a.band_h;
     const int lo = max(yb, a.row0), hi = min(yb + a.band_h, a.row1);
     const int ybase = yb + r;
     const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
@@ -696,7 +697,12 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
         attr_done = true;
     }
-    const int rows = a.row1 - a.row0;
+    // Bands are laid out from row0 rounded down to a multiple of 2S.  (They used to be aligned to
+    // multiples of band_h in global rows: a strip that does not start on such a multiple then got one
+    // band more than this heuristic planned, 780 workgroups for 768 slots, i.e. a second round --
+    // interior ranks of a row-strip run paid 1.23 ms per frame instead of 0.96.)
+    a.band_base = a.row0 / (2 * S) * (2 * S);
+    const int rows = a.row1 - a.band_base;
     a.nstrips = (a.g.W + C::CW - 1) / C::CW;
     // one resident wave of workgroups: WG_PER_CU per CU (LDS-limited) x 256 CUs
     const int per_band = a.nstrips * S;
@@ -721,7 +727,7 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
         if (h == unit) break;
     }
     a.band_h = bh;
-    const int nbands = (a.row1 - 1) / bh - a.row0 / bh + 1;     // bands are globally aligned
+    const int nbands = (rows + bh - 1) / bh;
     a.nblocks = nbands * per_band;
     a.per_xcd = (a.nblocks + kXcds - 1) / kXcds;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S, NP>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES, stream, a);
@@ -766,7 +772,7 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     a.in = (const float4*)in; a.nd = (const float4*)f->nd; a.out = (float4*)out;
     a.row0 = row0; a.row1 = row1; a.step = s;
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z; a.sigma_l = p->sigma_l;
-    a.band_h = a.nstrips = a.nblocks = a.per_xcd = 0;
+    a.band_h = a.band_base = a.nstrips = a.nblocks = a.per_xcd = 0;
 
     int variant = p->atrous_variant;
     if (variant == 0) variant = (iteration <= 4) ? 3 : 1;
