@@ -1,33 +1,56 @@
-// main.cpp — same CLI contract as the reference's src/main.cpp:5-40: `-t [label]` runs the
-// registered tests whose name matches the regex label (all when omitted), `-h` prints help.
-// Unlike the reference the exit status reports failed tests.
-#include <cstring>
-#include <iostream>
+// main.cpp — command line of the host harness.  It honours the contract of the reference's
+// src/main.cpp:5-40 (`-t [label]` runs the registered tests whose name matches the regex label, all of
+// them when the label is omitted; `-h` prints the help and exits with 1; no arguments = help), and adds
+// what a build check needs: several `-t` in one call and an exit status that reports failed tests.
+#include <cstdio>
+#include <string>
+#include <vector>
 
 #include "test.h"
 
-static void usage(const char* prog)
+namespace {
+
+struct Request {
+    std::vector<std::string> labels;     // one regex per -t (".*" when -t came without a label)
+    bool help = false;
+    std::vector<std::string> unknown;
+};
+
+Request parse(const std::vector<std::string>& args)
 {
-    std::cout << "Usage: " << prog << " [options]\n"
-              << "Options:\n"
-              << "  -t [label]   Run tests (all or specific label)\n"
-              << "  -h           Show this help message\n";
+    Request r;
+    for (size_t k = 0; k < args.size(); ++k) {
+        const std::string& a = args[k];
+        if (a == "-h") {
+            r.help = true;
+        } else if (a == "-t") {
+            const bool has_label = k + 1 < args.size() && !args[k + 1].empty() && args[k + 1][0] != '-';
+            r.labels.push_back(has_label ? args[++k] : std::string(".*"));
+        } else {
+            r.unknown.push_back(a);
+        }
+    }
+    return r;
 }
+
+int help(const char* prog)
+{
+    std::printf("Usage: %s [options]\n"
+                "Options:\n"
+                "  -t [label]   Run tests (all or specific label)\n"
+                "  -h           Show this help message\n"
+                "Exit status: 0 all selected tests passed, 1 help shown, 2 a test failed.\n", prog);
+    return 1;
+}
+
+}  // namespace
 
 int main(int argc, char* argv[])
 {
-    if (argc < 2) { usage(argv[0]); return 1; }
+    const Request req = parse(std::vector<std::string>(argv + 1, argv + argc));
+    for (const std::string& u : req.unknown) std::fprintf(stderr, "Unknown option: %s\n", u.c_str());
+    if (req.help || (req.labels.empty() && req.unknown.empty())) return help(argv[0]);
     int failed = 0;
-    for (int i = 1; i < argc; ++i) {
-        if (!strcmp(argv[i], "-t")) {
-            if (i + 1 < argc && argv[i + 1][0] != '-') failed += test(argv[++i]);
-            else failed += test();
-        } else if (!strcmp(argv[i], "-h")) {
-            usage(argv[0]);
-            return 1;
-        } else {
-            std::cerr << "Unknown option: " << argv[i] << std::endl;
-        }
-    }
+    for (const std::string& label : req.labels) failed += test(label);
     return failed ? 2 : 0;
 }
