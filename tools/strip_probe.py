@@ -21,14 +21,22 @@ p = rmd.default_params()
 p.max_motion_rows = 8
 
 
+SYNC = None
+
+
 def run(make, px):
+    global SYNC
+    SYNC = None
     den, frames = make()
+    sync = SYNC if SYNC else (lambda: None)
     for f in range(WARM):
         den(*frames[f % len(frames)])
+    sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for f in range(WARM, WARM + FRAMES):
         den(*frames[f % len(frames)])
+    sync()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / FRAMES
     return ms, px / ms / 1e3
@@ -40,7 +48,9 @@ def single():
 
 
 def strip():
-    sd = sharding.ShardedDenoiser(7680, 1080 * N, params=p, rank=R, world=N)
+    sd = sharding.ShardedDenoiser(7680, 1080 * N, params=p, rank=R, world=N, pipelined=os.environ.get("PROBE_PIPELINE", "0") == "1")
+    global SYNC
+    SYNC = sd.synchronize
     print(f"rank {R} of {N}: output rows [{sd.plan.row0}, {sd.plan.row1}), buffer rows [{sd.plan.buf_row0}, {sd.plan.buf_row0 + sd.plan.buf_rows})")
     return sd.denoise, [sd.synth(f) for f in range(WARM + FRAMES)]
 
