@@ -7,9 +7,13 @@
 A "step" is one frame: T + V + 5 x A over the whole frame (7 kernel launches), inputs resident in
 HBM before the timed region (all W+K frames of G-buffer are pre-generated on the device).
   N = 1 : BASELINE.json configs[2], 3840x2160 synthetic G-buffer + radiance, fp32.
-  N > 1 : weak scaling, one 7680x1080 row strip (the pixel count of a 4K frame) per GPU, i.e. a
-          7680 x 1080N frame (N = 4 is exactly the 8K frame of configs[3]); ranks exchange the
-          history halo rows with rank+-1 over RCCL every frame (sharding.py).
+  N > 1 : BASELINE.json configs[3], the fixed 7680x4320 (8K) frame cut into N row strips of 4320/N
+          rows, one per GPU (STRONG scaling); ranks exchange the history halo rows with rank+-1
+          over RCCL every frame (sharding.py).  Rank 0 also times the unsharded 8K frame on its
+          own GPU after the timed region (`one_gpu_same_frame`), so the speed-up is on one workload.
+Without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the parent starts
+the N ranks itself as child processes BEFORE anything touches the GPU, relays rank 0's JSON line
+and exits non-zero if any rank fails.
 Rank 0 prints ONE JSON line.  `value` = Mpixels/s of the whole job.  `roofline` is measured live
 with HIP events around single launches of the dominant kernel (the a-trous iteration: 48 B/px
 algorithmic = 32 read + 16 written).  `cpu_baseline` times the scalar oracle
@@ -28,7 +32,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 ATROUS_BYTES_PER_PX = 48       # per iteration: color 16 + nd 16 read, color 16 written
-FULL_BYTES_PER_PX = 424        # T 120 + V 64 + 5 x 48
+FULL_BYTES_PER_PX = 424        # T 120 + V 64 + 5 x 48, every pass priced on its own
+MOVED_BYTES_PER_PX = 376       # what rmd_svgf_frame moves: T 120 + 16 (it also writes v_color), V ~0 (flagged tiles only), 5 x 48
 MAX_RESIDENT = 64              # pre-generated G-buffer frames kept in HBM
 
 
@@ -40,7 +45,70 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-sizes", action="store_true")
     ap.add_argument("--roofline-reps", type=int, default=30)
+    ap.add_argument("--rehearse-launcher", action="store_true",
+                    help="start the ranks, rendezvous, reduce one number, print a JSON line; no GPU work (CPU test of the launcher)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher: start N ranks as fresh child processes (one per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and relay rank 0's output.
+    Runs before torch or librmd are imported: the parent never touches the GPU and nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
+    import threading
+
+    def relay():                            # rank 0 prints the one JSON line; everything else goes to stderr
+        for line in procs[0].stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    rc, deadline = 0, time.time() + float(os.environ.get("RMD_BENCH_LAUNCH_TIMEOUT", "900"))
+    while any(pr.poll() is None for pr in procs):
+        failed = [pr.returncode for pr in procs if pr.poll() not in (None, 0)]
+        if failed or time.time() > deadline:
+            rc = (failed[0] if failed and failed[0] > 0 else 1)
+            for pr in procs:                # a rank died: the others would wait in a collective forever
+                if pr.poll() is None:
+                    pr.terminate()
+            break
+        time.sleep(0.1)
+    for pr in procs:
+        try:
+            pr.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+        if pr.returncode != 0 and rc == 0:
+            rc = pr.returncode if pr.returncode > 0 else 1
+    reader.join(timeout=5)
+    return rc
+
+
+def rehearse_launcher(args):
+    """The ranks' side of --rehearse-launcher: rendezvous over gloo, one MAX all-reduce, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    if os.environ.get("RMD_BENCH_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launcher_rehearsal": True, "n_gpus": world, "max_over_ranks": float(t.item())}), flush=True)
+    dist.destroy_process_group()
 
 
 def hip_event_ms(rmd, fn, reps):
@@ -119,7 +187,8 @@ def other_size(rmd, torch, width, height, p, frames=16, warm=4):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"mpix_s": round(width * height * frames / dt / 1e6, 1), "ms_per_frame": round(dt / frames * 1e3, 4),
-            "effective_GBps": round(FULL_BYTES_PER_PX * width * height * frames / dt / 1e9, 1), "frames": frames}
+            "effective_GBps": round(FULL_BYTES_PER_PX * width * height * frames / dt / 1e9, 1),
+            "moved_GBps": round(MOVED_BYTES_PER_PX * width * height * frames / dt / 1e9, 1), "frames": frames}
 
 
 def reference_api_kernels(rmd, torch, width=3840, height=2160):
@@ -201,6 +270,10 @@ def cpu_baseline():
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    if args.rehearse_launcher:
+        return rehearse_launcher(args)
     import torch
     import torch.distributed as dist
     import raymarchdenoisercuda_amd as rmd        # ImportError if librmd.so is missing: there is no fallback
@@ -230,9 +303,9 @@ def main():
         width, height = 3840, 2160
         workload = "3840x2160 synthetic G-buffer + radiance, full SVGF fp32 (BASELINE configs[2])"
     else:
-        width, height = 7680, 1080 * world
-        workload = (f"7680x{height} synthetic G-buffer, one 7680x1080 row strip per GPU (weak scaling; "
-                    "4 GPUs = the 8K frame of BASELINE configs[3]), full SVGF fp32, RCCL neighbour history halo")
+        width, height = 7680, 4320
+        workload = (f"7680x4320 (8K) synthetic G-buffer in {world} row strips of {height // world} rows, one per GPU "
+                    "(BASELINE configs[3], strong scaling), full SVGF fp32, RCCL neighbour history halo over xGMI")
     p = rmd.default_params()
     p.max_motion_rows = 8            # the synthetic pan moves <= 1.5 rows per frame
     p.atrous_variant = int(os.environ.get("RMD_ATROUS_VARIANT", "0"))   # 0 = library default (experiments only)
@@ -285,15 +358,20 @@ def main():
         # BASELINE.json's metric string (the variance pass is part of "full SVGF": T + V + 5 x A)
         "metric": "Mpixels/s full SVGF (temporal+5 à-trous) at 1080p/4K; achieved HBM GB/s vs peak",
         "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "frame": [width, height], "rows_per_gpu": rows_out,
                    "parallelism": f"row-strip x{world}", "passes": "T + V + 5 x A (7 launches/frame)",
                    "frame_pipelining": "T+V of frame k+1 overlap A1..A4 of frame k (2 streams)" if pipelined else "none"},
+        # 424 B/px is SURVEY §8(d)'s per-pass algorithmic count; with V's pass-through copy fused into T the
+        # frame actually moves 376 B/px, which is the figure to hold against the HBM peak
         "effective_GBps_full_svgf": round(FULL_BYTES_PER_PX * total_px / dt / 1e9, 1),
+        "moved_GBps_full_svgf": round(MOVED_BYTES_PER_PX * total_px / dt / 1e9, 1),
+        "bytes_per_px": {"algorithmic_per_pass_sum": FULL_BYTES_PER_PX, "moved_with_V_fused_into_T": MOVED_BYTES_PER_PX},
     }
     if world > 1:
         result["halo_bytes_per_frame_rank0"] = sharding.halo_bytes(plan, width)
+        result["config"]["redundant_rows_per_side"] = {"inputs": plan.reach_in, "history": plan.reach_hist}
 
     if rank == 0:
         result["roofline"] = measure_roofline(rmd, torch, sd.den, frames, width, rows_out, plan, args.roofline_reps)
@@ -305,6 +383,12 @@ def main():
         result["other_sizes"] = {f"{w}x{h}": other_size(rmd, torch, w, h, p, frames=n, warm=wu)
                                  for w, h, n, wu in ((1920, 1080, 48, 8), (7680, 4320, 16, 4))}
         result["reference_api"] = reference_api_kernels(rmd, torch)
+    if world > 1 and rank == 0 and not args.no_other_sizes:
+        # the SAME 8K frame unsharded on rank 0's GPU: what the N-GPU figure is a speed-up over
+        del frames, sd
+        torch.cuda.empty_cache()
+        one = other_size(rmd, torch, width, height, p, frames=8, warm=3)
+        result["one_gpu_same_frame"] = dict(one, speedup=round(value / one["mpix_s"], 3))
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,42 @@
+"""bench.py --gpus N without a launcher: the parent starts the N ranks itself (before anything touches
+the GPU), relays rank 0's JSON line and reports a failing rank through its exit status.  Rehearsed on
+CPU with --rehearse-launcher (ranks rendezvous over gloo and reduce one number; no GPU work)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*argv, **env):
+    e = dict(os.environ, **env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)                      # the shape of the driver's N = 1 command: no launcher environment
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_parent_starts_the_ranks_and_relays_rank0():
+    r = run_bench("--gpus", "3", "--rehearse-launcher")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    assert got == {"launcher_rehearsal": True, "n_gpus": 3, "max_over_ranks": 3.0}
+
+
+def test_a_failing_rank_fails_the_run():
+    r = run_bench("--gpus", "2", "--rehearse-launcher", RMD_BENCH_FAIL_RANK="1")
+    assert r.returncode == 3
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_launcher_does_not_import_torch_or_the_library_in_the_parent():
+    """The parent must not touch the GPU: everything before launch_ranks() is standard library."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def main()")]
+    for line in head.splitlines():
+        assert not line.startswith(("import torch", "from torch", "import raymarchdenoisercuda_amd")), line
+    body = src[src.index("def main()"):]
+    assert body.index("launch_ranks(args)") < body.index("import torch")

@@ -368,6 +368,25 @@ def test_row_strips_are_bit_identical_to_one_gpu(rmd, cuda, world, height):
         assert torch.equal(got[f], want[f]), f"world {world} frame {f}: {(got[f] != want[f]).sum().item()} values differ"
 
 
+def test_8k_frame_in_8_row_strips_is_bit_identical_to_one_gpu(rmd, cuda):
+    """BASELINE configs[3] at its own size: the 7680x4320 frame cut into 8 strips of 540 rows (what
+    `bench.py --gpus 8` runs, one strip per rank) gives the bits of the unsharded 8K frame, over
+    3 frames so the exchanged history halo rows are read back by the temporal pass."""
+    width, height, world, frames = 7680, 4320, 8, 3
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    single = rmd.SvgfDenoiser(width, height, params=p)
+    want = []
+    for f in range(frames):
+        c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
+        want.append(single.denoise(c, nd, m).clone())
+    del single
+    got = simulate_strips(rmd, width, height, world, frames, p)
+    torch.cuda.synchronize()
+    for f in range(frames):
+        assert torch.equal(got[f], want[f]), f"frame {f}: {(got[f] != want[f]).sum().item()} values differ"
+
+
 def test_synth_generator_matches_oracle_bitwise(rmd, orc, cuda):
     for (w, h, f) in [(64, 48, 0), (300, 70, 7), (523, 301, 59)]:
         c, nd, m, al = rmd.svgf.synth_gbuffer(w, h, f, want_albedo=True)
