@@ -18,6 +18,7 @@ W, H = (int(os.environ.get("PROBE_W", 3840)), int(os.environ.get("PROBE_H", 2160
 raw = C.CDLL(rmd.LIB_PATH)
 p = rmd.default_params()
 p.max_motion_rows = 8
+p.atrous_variant = int(os.environ.get("PROBE_VARIANT", "0"))
 den = rmd.SvgfDenoiser(W, H, params=p)
 frames = [rmd.svgf.synth_gbuffer(W, H, f) for f in range(3)]
 for c, nd, m in frames:
@@ -26,14 +27,21 @@ torch.cuda.synchronize()
 c, nd, m = frames[-1]
 desc = den.describe(c, nd, m, den.ping[1])
 NWG = 8192
-buf = np.zeros((NWG, 4), np.uint64)
+PH = os.environ.get("RMD_TRACE_PHASES") is not None
+buf = np.zeros(NWG * (14 if PH else 6), np.uint64)
 src, dst = den.v_color, den.ping[0]
 for it in range(5):
     for rep in range(2):                      # warm, then the launch that is read back (read clears)
         rmd.svgf.atrous(desc, p, it, src, dst, 0, H)
         assert raw.rmd_debug_atrous_trace(buf.ctypes.data_as(C.c_void_p), NWG) == 0
     src, dst = dst, (den.ping[1] if dst is den.ping[0] else den.ping[0])
-    t = buf[buf[:, 0] > 0]
+    rec = buf[:NWG * 6].reshape(NWG, 6)
+    if PH:
+        phs = buf[NWG * 6:].reshape(NWG, 8)[rec[:, 0] > 0][:, :5].astype(np.float64)
+        tot = phs.sum(axis=1, keepdims=True)
+        frac = np.median(phs / np.maximum(tot, 1), axis=0)
+        print("    wave-0 time split (median over workgroups): issue loads %.3f  compute %.3f  barrier1 %.3f  store %.3f  barrier2 %.3f" % tuple(frac))
+    t = rec[rec[:, 0] > 0]
     t0 = t[:, 0].min()
     start, end = (t[:, 0] - t0).astype(np.int64), (t[:, 1] - t0).astype(np.int64)
     dur = end - start
@@ -58,5 +66,10 @@ for it in range(5):
     print(f"    per-CU last end us: p10 {np.percentile(cu_end, 10):.1f}  p50 {np.percentile(cu_end, 50):.1f}  p90 {np.percentile(cu_end, 90):.1f}  max {cu_end.max():.1f}")
     late = start > np.percentile(end, 10)
     print(f"    workgroups that start after the first 10% have ended: {late.sum()}")
+    cyc, rows = t[:, 4].astype(np.float64), t[:, 5].astype(np.float64)
+    ghz = cyc / np.maximum(dur, 1) * 0.1
+    sel = ~edge
+    print(f"    shader clock while resident: p50 {np.percentile(ghz, 50):.2f} GHz (p10 {np.percentile(ghz, 10):.2f}, p90 {np.percentile(ghz, 90):.2f}); "
+          f"interior workgroups: {np.percentile(cyc[sel] / rows[sel], 50):.0f} cycles per lattice row of 128 px (p90 {np.percentile(cyc[sel] / rows[sel], 90):.0f})")
     occ = (dur.sum() / max(end.max(), 1)) / (len(per_cu) * 3)
     print(f"    average resident workgroups / (CUs x 3): {occ:.3f}")
