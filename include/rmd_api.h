@@ -98,7 +98,25 @@ int rmd_filter_tiled(rmd_gbuffer frame, rmd_filter_params params, void* stream);
 /* ---- SVGF (north_star hot path; the reference only names it: README.md:3-10) ------------ */
 
 /* Parameters of the three SVGF passes.  Semantics: SURVEY.md Appendix A (normative for this
- * build).  rmd_svgf_default_params() fills the defaults quoted there. */
+ * build).  rmd_svgf_default_params() fills the defaults quoted there.
+ *
+ * Input contract.  nd.xyz of every pixel is a UNIT normal or exactly (0,0,0) ("no surface"; the
+ * Cornell normal plane is 65 % zeros).  The kernels evaluate max(0, n.n')^sigma_n with
+ * the cosine clamped to [0,1] and take "1 - n.n" as the test for a zero tap normal, so normals of
+ * any other length get other weights in the a-trous passes than in the variance pass and the
+ * oracle.  rmd_convert_u8_to_f32(renormalize_xyz = 1) and rmd_synth_gbuffer produce conforming
+ * planes; CudaGBuffer::openImages uses the former.
+ *
+ * Conditioning (the one region where parity with the oracle is NOT claimed).  The luminance edge
+ * weight is exp(-|dl| / (sigma_l * sqrt(var) + 1e-8)).  Where the variance channel is exactly 0 --
+ * alpha_moments = 1 (moments never accumulate: m2 - m1^2 = 0), or var_radius = 0 on frames without
+ * history -- the denominator is 1e-8 and the weight is a step function of the LAST BIT of dl: two
+ * taps pass only if their luminances are equal to within ~1e-8, and whether they are is decided
+ * by the rounding of the previous iteration (division vs reciprocal, order of summation).  Any two
+ * correct implementations then differ on isolated pixels; this one stays within 5e-2 (1 + |ref|) of
+ * the oracle there, with > 99.9 % of the values within the usual 5e-4 (1 + |ref|)
+ * (tests/test_svgf_gpu.py::test_zero_variance_settings_are_fenced).  The settings are accepted:
+ * the result is a valid edge-stopped filter, just not a reproducible one to the last digits. */
 typedef struct rmd_svgf_params {
     /* T: temporal reprojection + accumulation */
     float alpha_color;      /* 0.05  minimum blend weight of the new colour sample             */
@@ -117,7 +135,11 @@ typedef struct rmd_svgf_params {
     float sigma_l;          /* 4   */
     int   iterations;       /* 5   step 2^i for i in [0, iterations)                           */
     int   hist_iteration;   /* 0   output of this iteration becomes next frame's hist_color    */
-    int   atrous_variant;   /* 0 auto | 1 direct (global loads) | 2 LDS row-streaming           */
+    int   atrous_variant;   /* 0 auto (= 3 for iterations 0..4, 1 beyond) | row-pair formulation: 1 direct
+                                   (taps from global memory, any step), 2 / 3 LDS row streaming with one / two row
+                                   pairs per workgroup | pixel-pair formulation: 4 LDS row streaming, 5 direct.
+                                   1, 2, 3 give identical bits, so do 4 and 5 (the two families differ in the
+                                   order of summation, i.e. by rounding)                                  */
     int   tv_workgroups;    /* 0   T and V as one workgroup per 64x4 tile (default, fastest) | N > 0: N persistent
                                    workgroups that walk the tiles: a constant register footprint beside another
                                    frame's a-trous launches (experimental, slower so far); same results either way */

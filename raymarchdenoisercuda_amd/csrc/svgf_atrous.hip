@@ -234,7 +234,9 @@ __device__ __forceinline__ float4 finish(float sw, float sl, float sr, float sg,
         const float inv = fast_rcp(sw);
         L = sl * inv; R = sr * inv; G = sg * inv; V = sv * inv * inv;
     }
-    const float B = fma_(-kLumG, G, fma_(-kLumR, R, L)) * (1.0f / kLumB);
+    // blue is recovered from the luminance sum; the recovery amplifies the rounding of L by 1/0.0722, so
+    // a true blue of 0 could come out as a tiny negative value and be fed back as history: clamped
+    const float B = fmaxf(fma_(-kLumG, G, fma_(-kLumR, R, L)) * (1.0f / kLumB), 0.0f);
     return make_float4(R, G, B, V);
 }
 
@@ -243,6 +245,9 @@ __device__ __forceinline__ float4 finish(float sw, float sl, float sr, float sg,
 // (100 MHz s_memrealtime), placement (XCC_ID, HW_ID) and code path of the LAST stream launch
 __device__ unsigned long long g_atrous_trace[6 * 8192];
 __device__ unsigned long long g_atrous_phase[8 * 8192];     // per workgroup (wave 0): cycles in load issue / compute / barrier 1 / store / barrier 2
+#define RMD_PHASE(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tp; tp = tn_; }
+#else
+#define RMD_PHASE(i)
 #endif
 
 // ---------------------------------------------------------------------------------- direct
@@ -617,19 +622,31 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     const int span = jhi - j0;
     const int jq1 = j0 + span * RMD_PRIO_T1 / 16, jq2 = j0 + span * RMD_PRIO_T2 / 16, jq3 = j0 + span * RMD_PRIO_T3 / 16;
     __builtin_amdgcn_s_setprio(3);
+#ifdef RMD_ATROUS_TRACE
+    unsigned long long ph[5] = { 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
+#endif
     for (int j = j0; j < jhi; j += C::ADV) {
         if (j >= jq3)      __builtin_amdgcn_s_setprio(0);
         else if (j >= jq2) __builtin_amdgcn_s_setprio(1);
         else if (j >= jq1) __builtin_amdgcn_s_setprio(2);
         const bool more = j + C::ADV < jhi;
         if (more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute
+        RMD_PHASE(0)
         compute(j);
+        RMD_PHASE(1)
         if (!more) { write_out(j); break; }
         __syncthreads();                                     // every wave is done reading the ADV oldest rows
+        RMD_PHASE(2)
         store_rows(j - 2 + C::NR); store_aux();
         write_out(j);
+        RMD_PHASE(3)
         __syncthreads();
+        RMD_PHASE(4)
     }
+#ifdef RMD_ATROUS_TRACE
+    if (tid == 0 && blockIdx.x < 8192)
+        for (int i = 0; i < 5; ++i) g_atrous_phase[8 * blockIdx.x + i] = ph[i];
+#endif
 }
 
 
@@ -1215,9 +1232,6 @@ __device__ __forceinline__ void atrous_pair_body(const AtrousArgs& a, unsigned c
     __builtin_amdgcn_s_setprio(3);
 #ifdef RMD_ATROUS_TRACE
     unsigned long long ph[5] = { 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
-#define RMD_PHASE(i) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); ph[i] += tn_ - tp; tp = tn_; }
-#else
-#define RMD_PHASE(i)
 #endif
     for (int j = j0; j < jhi; j += C::ADV) {
         if (j >= jq3)      __builtin_amdgcn_s_setprio(0);
