@@ -13,7 +13,7 @@ LIB      := $(LIBDIR)/librmd.so
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-variable \
             -Wno-unused-but-set-variable
 KERNELS  := $(CSRC)/runtime.hip $(CSRC)/box_filter.hip $(CSRC)/weighted_filter.hip $(CSRC)/svgf_temporal.hip $(CSRC)/svgf_variance.hip \
-            $(CSRC)/svgf_atrous.hip $(CSRC)/svgf_frame.hip $(CSRC)/convert_synth.hip
+            $(CSRC)/svgf_atrous.hip $(CSRC)/svgf_frame.hip $(CSRC)/convert_synth.hip $(CSRC)/strips.hip
 OBJS     := $(patsubst $(CSRC)/%.hip,build/%.o,$(KERNELS))
 
 HOSTSRC  := $(wildcard $(PKG)/host/*.cpp)
@@ -29,7 +29,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rmd_api.h Makefile
 
 $(LIB): $(OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl
 
 oracle:
 	$(MAKE) -C oracle

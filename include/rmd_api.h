@@ -36,6 +36,7 @@ extern "C" {
 #define RMD_E_ROWS         (-5)  /* row range outside the frame or not covered by the buffer */
 #define RMD_E_UNSUPPORTED  (-6)  /* filter type declared by the reference but not built yet  */
 #define RMD_E_ALIGN        (-7)  /* plane pointer not aligned for its vector type            */
+#define RMD_E_COMM         (-8)  /* RCCL is missing or a collective call failed              */
 
 /* ---- PODs mirroring the reference host structs ------------------------------------------ */
 typedef struct rmd_int2   { int x, y; } rmd_int2;
@@ -226,11 +227,64 @@ int  rmd_svgf_context_history(rmd_svgf_context* ctx, float** hist_color, float**
 /* Fill a descriptor with the context's planes for the next frame (advanced use / tests). */
 int  rmd_svgf_context_describe(rmd_svgf_context* ctx, rmd_svgf_frame_desc* f);
 
+/* ---- row strips across the GPUs of a node (the reference is single-device) ----- */
+/* A frame of `height` rows is cut into `world` contiguous full-width row strips, one per GPU.  A rank
+ * runs rmd_svgf_frame on its strip plus the rows later passes tap (redundant rows, no exchange inside a
+ * frame); only the temporal feedback crosses ranks: the history rows beyond what a rank produces
+ * itself, point to point with rank +- 1.  The planning functions are pure arithmetic (no device). */
+typedef struct rmd_strip_plan {
+    int height, world, rank;
+    int row0, row1;            /* owned output rows [row0,row1)                                    */
+    int buf_row0, buf_rows;    /* rows every plane of this rank holds (strip + reach, clamped)      */
+    int reach_in, reach_hist;  /* rmd_svgf_frame_reach()[0], [1]                                     */
+    int have_color, have_moments; /* ...[2], [3]: history rows this rank produces beyond its strip   */
+} rmd_strip_plan;
+enum { RMD_HALO_RECV = 0, RMD_HALO_SEND = 1, RMD_HALO_MAX_STEPS = 8 };
+typedef struct rmd_halo_step {
+    int kind;                  /* RMD_HALO_RECV | RMD_HALO_SEND                                      */
+    int plane;                 /* 0 = hist_color, 1 = hist_moments                                   */
+    int row_lo, row_hi;        /* GLOBAL rows [row_lo,row_hi)                                        */
+    int peer;                  /* rank - 1 or rank + 1                                               */
+} rmd_halo_step;
+int    rmd_strip_rows(int height, int world, int rank, int* row0, int* row1);
+/* RMD_E_ROWS if a strip would be shorter than the history reach (use fewer ranks). */
+int    rmd_strip_plan_make(int height, int world, int rank, const rmd_svgf_params* p, rmd_strip_plan* out);
+/* The exchange of one rank and frame.  Receives and the neighbour's matching sends appear in the same
+ * order, so posting them as one group cannot deadlock.  steps may be NULL to count. */
+int    rmd_halo_plan(const rmd_strip_plan* plan, rmd_halo_step* steps, int max_steps, int* n_steps);
+size_t rmd_halo_bytes(const rmd_strip_plan* plan, int width);   /* bytes this rank receives per frame */
+
+/* RCCL communicator (librccl.so is opened on first use; rmd_comm_available() == 0 without it).
+ * Multi-process: rank 0 calls rmd_comm_unique_id and hands the 128 bytes to the other ranks (the host
+ * program's job: a file, a socket, MPI); every rank calls rmd_comm_create on its own device.
+ * Single process, several GPUs: rmd_comm_create_all (ncclCommInitAll). */
+typedef struct rmd_comm rmd_comm;
+int rmd_comm_available(void);
+int rmd_comm_unique_id(void* id128);
+int rmd_comm_create(const void* id128, int world, int rank, rmd_comm** out);
+int rmd_comm_create_all(int ndev, const int* devices /* NULL = 0..ndev-1 */, rmd_comm** out);
+int rmd_comm_destroy(rmd_comm* c);
+/* The per-frame history halo exchange of this rank: ncclGroupStart; ncclSend / ncclRecv(rank +- 1) of
+ * the rmd_halo_plan rows; ncclGroupEnd -- asynchronous on `stream`.  Call it between frame k's
+ * hist_iteration and frame k+1's temporal pass, on the planes rmd_svgf_context_history returns.
+ * world == 1 (or an empty plan) is a no-op and needs no communicator. */
+int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* hist_color, float* hist_moments, void* stream);
+/* Single-process form: plans[k], planes and stream of rank k for k < world, all ranks in one group. */
+int rmd_halo_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* hist_color,
+                          float* const* hist_moments, void* const* streams);
+/* Explicit steps on communicator comm_index of c (tests: a loop-back exchange on one GPU). */
+int rmd_halo_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
+                            int width, float* hist_color, float* hist_moments, void* stream);
+
 /* ---- 8-bit <-> float plane conversion --------------------------------- */
 /* uchar4 -> float4, c/255; optional per-pixel renormalisation of xyz (for normals). */
 int rmd_convert_u8_to_f32(const rmd_uchar4* in, float* out, size_t pixels, int renormalize_xyz, float w_value, void* stream);
 /* float4 illumination (x optional float4 albedo) -> clamp -> uchar4. */
 int rmd_convert_f32_to_u8(const float* in, const float* albedo, rmd_uchar4* out, size_t pixels, void* stream);
+/* Demodulation by albedo BEFORE filtering (the render / albedo planes of reference include/gbuffer.h:10-12
+ * imply the split): out.rgb = radiance.rgb / max(albedo.rgb, eps), out.w = radiance.w.  SVGF then filters
+ * illumination and rmd_convert_f32_to_u8(..., albedo, ...) multiplies the albedo back.  in == out is allowed. */
+int rmd_demodulate(const float* radiance, const float* albedo, float* out, size_t pixels, float eps, void* stream);
 
 /* ---- synthetic G-buffer generator (SURVEY §8d "Synthetic inputs") ------------------------ */
 typedef struct rmd_synth_desc {
@@ -262,6 +316,7 @@ int  rmd_stream_sync(void* stream);
 int  rmd_event_create(void** event);
 int  rmd_event_destroy(void* event);
 int  rmd_event_record(void* event, void* stream);
+int  rmd_event_synchronize(void* event);   /* host waits for the event (e.g. an upload queued by openImages) */
 int  rmd_stream_wait_event(void* stream, void* event);
 int  rmd_device_sync(void);              /* reference cudaDeviceSynchronize(), src/test.cu:77,89 */
 int  rmd_device_count(int* count);

@@ -1,0 +1,125 @@
+// strips.h — C++ face of the row-strip / multi-GPU part of the C ABI (rmd_strip_* / rmd_halo_* / rmd_comm_* in
+// rmd_api.h).  Nothing like it exists in the reference (one device, default stream: SURVEY §0.4).
+//
+//   StripPlan plan(height, world, rank, params);     which rows this rank owns / holds / exchanges
+//   NodeDenoiser node(width, height, params, devices);   one process driving several GPUs of a node:
+//       node.denoise(color, nd, motion, prevNd, out) runs every rank's strip on its own device and
+//       stream and then the neighbour history-halo exchange (RCCL over xGMI; ranks that share a device
+//       -- a rehearsal on one GPU -- copy the rows device-to-device by the same plan).
+// A multi-PROCESS host (one rank per process) uses StripPlan + SvgfContext + rmd_comm_create /
+// rmd_halo_exchange directly: INTEGRATION.md shows the loop.
+#ifndef RMD_STRIPS_H
+#define RMD_STRIPS_H
+
+#include <memory>
+#include <vector>
+
+#include "svgf.h"
+
+struct StripPlan : rmd_strip_plan {
+    StripPlan() : rmd_strip_plan{} {}
+    StripPlan(int height, int world, int rank, const SvgfParams& p) { rmdCheck(rmd_strip_plan_make(height, world, rank, &p, this), "StripPlan"); }
+    std::vector<rmd_halo_step> haloSteps() const
+    {
+        std::vector<rmd_halo_step> s(RMD_HALO_MAX_STEPS);
+        int n = 0;
+        rmdCheck(rmd_halo_plan(this, s.data(), (int)s.size(), &n), "StripPlan::haloSteps");
+        s.resize(n);
+        return s;
+    }
+    size_t haloBytes(int width) const { return rmd_halo_bytes(this, width); }
+};
+
+// RAII over rmd_comm (move-only)
+class Communicator {
+    rmd_comm* c = nullptr;
+public:
+    Communicator() = default;
+    explicit Communicator(const std::vector<int>& devices) { rmdCheck(rmd_comm_create_all((int)devices.size(), devices.data(), &c), "Communicator"); }
+    Communicator(const void* id128, int world, int rank) { rmdCheck(rmd_comm_create(id128, world, rank, &c), "Communicator"); }
+    Communicator(const Communicator&) = delete;
+    Communicator& operator=(const Communicator&) = delete;
+    Communicator(Communicator&& o) noexcept : c(o.c) { o.c = nullptr; }
+    Communicator& operator=(Communicator&& o) noexcept { if (this != &o) { rmd_comm_destroy(c); c = o.c; o.c = nullptr; } return *this; }
+    ~Communicator() { rmd_comm_destroy(c); }
+    rmd_comm* get() const { return c; }
+};
+
+// One process, `devices.size()` ranks: rank k runs on devices[k].  The planes handed to denoise() are per
+// rank and hold that rank's buffer rows [plan.buf_row0, plan.buf_row0 + plan.buf_rows).
+class NodeDenoiser {
+public:
+    struct Rank {
+        int device = 0;
+        StripPlan plan;
+        std::unique_ptr<SvgfContext> ctx;
+        void* stream = nullptr;
+    };
+    std::vector<Rank> ranks;
+
+    NodeDenoiser(int width, int height, const SvgfParams& p, const std::vector<int>& devices) : width_(width), params_(p)
+    {
+        const int world = (int)devices.size();
+        bool distinct = true;
+        for (int a = 0; a < world; ++a) for (int b = a + 1; b < world; ++b) distinct = distinct && devices[a] != devices[b];
+        ranks.resize(world);
+        for (int k = 0; k < world; ++k) {
+            Rank& r = ranks[k];
+            r.device = devices[k];
+            r.plan = StripPlan(height, world, k, p);
+            rmdCheck(rmd_set_device(r.device), "NodeDenoiser(set device)");
+            r.ctx.reset(new SvgfContext(width, height, r.plan.buf_row0, r.plan.buf_rows));
+            rmdCheck(rmd_stream_create(&r.stream), "NodeDenoiser(stream)");
+        }
+        if (world > 1 && distinct) comm_ = Communicator(devices);      // RCCL: one communicator per device
+    }
+    NodeDenoiser(const NodeDenoiser&) = delete;
+    NodeDenoiser& operator=(const NodeDenoiser&) = delete;
+    ~NodeDenoiser()
+    {
+        for (Rank& r : ranks) { rmd_set_device(r.device); rmd_stream_sync(r.stream); rmd_stream_destroy(r.stream); r.ctx.reset(); }
+    }
+
+    // One frame: every rank's strip (asynchronous on its own stream), then the history halo for the next frame.
+    void denoise(const std::vector<const float*>& color, const std::vector<const float*>& nd, const std::vector<const float*>& motion,
+                 const std::vector<const float*>& prevNd, const std::vector<float*>& out)
+    {
+        const int world = (int)ranks.size();
+        for (int k = 0; k < world; ++k) {
+            Rank& r = ranks[k];
+            rmdCheck(rmd_set_device(r.device), "NodeDenoiser::denoise(set device)");
+            r.ctx->denoise(params_, color[k], nd[k], motion[k], prevNd[k], out[k], r.plan.row0, r.plan.row1, r.stream);
+        }
+        if (world == 1) return;
+        std::vector<float*> hc(world), hm(world);
+        for (int k = 0; k < world; ++k) rmdCheck(rmd_svgf_context_history(ranks[k].ctx->get(), &hc[k], &hm[k]), "NodeDenoiser(history)");
+        if (comm_.get()) {
+            std::vector<rmd_strip_plan> plans(world);
+            std::vector<void*> streams(world);
+            for (int k = 0; k < world; ++k) { plans[k] = ranks[k].plan; streams[k] = ranks[k].stream; }
+            rmdCheck(rmd_halo_exchange_all(comm_.get(), plans.data(), width_, hc.data(), hm.data(), streams.data()), "NodeDenoiser(exchange)");
+            return;
+        }
+        // ranks share a device (rehearsal): the same plan, rows copied device to device once every strip is done
+        for (Rank& r : ranks) rmdCheck(rmd_stream_sync(r.stream), "NodeDenoiser(sync)");
+        for (int k = 0; k < world; ++k)
+            for (const rmd_halo_step& s : ranks[k].plan.haloSteps()) {
+                if (s.kind != RMD_HALO_RECV) continue;
+                const Rank& q = ranks[s.peer];
+                float* dst = (s.plane == 0 ? hc[k] : hm[k]) + (size_t)(s.row_lo - ranks[k].plan.buf_row0) * width_ * 4;
+                const float* src = (s.plane == 0 ? hc[s.peer] : hm[s.peer]) + (size_t)(s.row_lo - q.plan.buf_row0) * width_ * 4;
+                rmdCheck(rmd_memcpy_d2d(dst, src, (size_t)(s.row_hi - s.row_lo) * width_ * 16, ranks[k].stream), "NodeDenoiser(copy)");
+            }
+    }
+    void synchronize()
+    {
+        for (Rank& r : ranks) { rmdCheck(rmd_set_device(r.device), "NodeDenoiser::synchronize"); rmdCheck(rmd_stream_sync(r.stream), "NodeDenoiser::synchronize"); }
+    }
+
+private:
+    int width_;
+    SvgfParams params_;
+    Communicator comm_;
+};
+
+#endif

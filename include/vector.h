@@ -2,7 +2,11 @@
 // reference's CudaVector<T> (include/vector.h:34-169) so its call sites port 1:1, but
 //   * move-only (the reference is implicitly copyable => double cudaFree),
 //   * every runtime call is checked (the reference checks none),
-//   * copyFrom/copyTo size mismatches throw std::runtime_error as in the reference (:143-151).
+//   * copyFrom(T*, n) accepts n <= size and throws std::runtime_error beyond it, as the reference
+//     does (:142-153).
+// CudaVector(T* v, n) follows what the reference's constructor DOES (:124-127: allocate n elements
+// and copy them from HOST pointer v), not its doc comment ("wraps an existing device pointer", :51-55);
+// the non-owning view of device memory is CudaVector<T>::wrap(devicePtr, n).
 #ifndef RMD_VECTOR_H
 #define RMD_VECTOR_H
 
@@ -25,8 +29,15 @@ private:
 public:
     CudaVector() = default;
     explicit CudaVector(size_t size) : size_p(size) { rmdCheck(rmd_malloc((void**)&data_p, size * sizeof(T)), "CudaVector"); }
-    CudaVector(T* v, size_t size) : data_p(v), size_p(size), owner(false) {}      // wraps, does not own
-    explicit CudaVector(const CpuVector<T>& v) : CudaVector(v.size()) { copyFrom(v); }
+    CudaVector(const T* hostData, size_t size) : CudaVector(size) { copyFrom(hostData, size); }   // reference :124-127
+    explicit CudaVector(const CpuVector<T>& v) : CudaVector(v.data(), v.size()) {}                // reference :130
+    // non-owning view of `size` elements of DEVICE memory (the destructor leaves them alone)
+    static CudaVector wrap(T* devicePtr, size_t size)
+    {
+        CudaVector v;
+        v.data_p = devicePtr; v.size_p = size; v.owner = false;
+        return v;
+    }
     CudaVector(const CudaVector&) = delete;
     CudaVector& operator=(const CudaVector&) = delete;
     CudaVector(CudaVector&& o) noexcept : data_p(o.data_p), size_p(o.size_p), owner(o.owner) { o.data_p = nullptr; o.size_p = 0; }
@@ -57,10 +68,19 @@ public:
         if (v.size() != size_p) throw std::runtime_error("CudaVector::copyFromAsync: size mismatch");
         rmdCheck(rmd_memcpy_h2d_async(data_p, v.data(), size_p * sizeof(T), stream), "CudaVector::copyFromAsync");
     }
-    void copyFrom(const T* host, size_t n)
+    void copyFrom(const T* host, size_t n)                                      // reference :142-146: n <= size
     {
-        if (n != size_p) throw std::runtime_error("CudaVector::copyFrom: size mismatch");
+        if (n > size_p) throw std::runtime_error("CudaVector::copyFrom: size mismatch");
         rmdCheck(rmd_memcpy_h2d(data_p, host, n * sizeof(T)), "CudaVector::copyFrom");
+    }
+    void copyFromAsync(const T* host, size_t n, void* stream = nullptr)         // reference :149-153
+    {
+        if (n > size_p) throw std::runtime_error("CudaVector::copyFromAsync: size mismatch");
+        rmdCheck(rmd_memcpy_h2d_async(data_p, host, n * sizeof(T), stream), "CudaVector::copyFromAsync");
+    }
+    void copyToAsync(T* host, void* stream = nullptr) const                     // reference :161-163
+    {
+        rmdCheck(rmd_memcpy_d2h_async(host, data_p, size_p * sizeof(T), stream), "CudaVector::copyToAsync");
     }
     void copyTo(CpuVector<T>& v) const
     {

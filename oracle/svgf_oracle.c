@@ -288,6 +288,19 @@ void orc_convert_u8_to_f32(const uint8_t* in, float* out, size_t pixels, int ren
     }
 }
 
+/* Demodulation by albedo: illumination = radiance / max(albedo, eps), w unchanged. */
+void orc_demodulate(const float* radiance, const float* albedo, float* out, size_t pixels, float eps)
+{
+    for (size_t i = 0; i < pixels; ++i) {
+        for (int ch = 0; ch < 3; ++ch) {
+            float a = albedo[i * 4 + ch];
+            if (!(a > eps)) a = eps;
+            out[i * 4 + ch] = radiance[i * 4 + ch] / a;
+        }
+        out[i * 4 + 3] = radiance[i * 4 + 3];
+    }
+}
+
 void orc_convert_f32_to_u8(const float* in, const float* albedo, uint8_t* out, size_t pixels)
 {
     for (size_t i = 0; i < pixels; ++i) {

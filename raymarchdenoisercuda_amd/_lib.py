@@ -67,6 +67,18 @@ class SvgfFrameDesc(C.Structure):
                 ("out_color", C.c_void_p), ("stats", C.c_void_p), ("v_tile_flags", C.c_void_p)]
 
 
+class StripPlan(C.Structure):
+    """include/rmd_api.h rmd_strip_plan (mirrors sharding.StripPlan)."""
+    _fields_ = [("height", C.c_int), ("world", C.c_int), ("rank", C.c_int), ("row0", C.c_int), ("row1", C.c_int),
+                ("buf_row0", C.c_int), ("buf_rows", C.c_int), ("reach_in", C.c_int), ("reach_hist", C.c_int),
+                ("have_color", C.c_int), ("have_moments", C.c_int)]
+
+
+class HaloStep(C.Structure):
+    RECV, SEND = 0, 1
+    _fields_ = [("kind", C.c_int), ("plane", C.c_int), ("row_lo", C.c_int), ("row_hi", C.c_int), ("peer", C.c_int)]
+
+
 class SynthDesc(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("buf_row0", C.c_int), ("buf_rows", C.c_int),
                 ("seed", C.c_uint32), ("frame", C.c_int), ("pan_x", C.c_float), ("pan_y", C.c_float)]
@@ -92,8 +104,21 @@ SYMBOLS = {
     "rmd_svgf_context_denoise": (C.c_int, [_P, C.POINTER(SvgfParams), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "rmd_svgf_context_history": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "rmd_svgf_context_describe": (C.c_int, [_P, C.POINTER(SvgfFrameDesc)]),
+    "rmd_strip_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rmd_strip_plan_make": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SvgfParams), C.POINTER(StripPlan)]),
+    "rmd_halo_plan": (C.c_int, [C.POINTER(StripPlan), C.POINTER(HaloStep), C.c_int, C.POINTER(C.c_int)]),
+    "rmd_halo_bytes": (C.c_size_t, [C.POINTER(StripPlan), C.c_int]),
+    "rmd_comm_available": (C.c_int, []),
+    "rmd_comm_unique_id": (C.c_int, [_P]),
+    "rmd_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
+    "rmd_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
+    "rmd_comm_destroy": (C.c_int, [_P]),
+    "rmd_halo_exchange": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, _P, _P, _P]),
+    "rmd_halo_exchange_all": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "rmd_halo_exchange_steps": (C.c_int, [_P, C.c_int, C.POINTER(HaloStep), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "rmd_convert_u8_to_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_float, _P]),
     "rmd_convert_f32_to_u8": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
+    "rmd_demodulate": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_float, _P]),
     "rmd_synth_gbuffer": (C.c_int, [C.POINTER(SynthDesc), _P, _P, _P, _P, _P]),
     "rmd_malloc": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "rmd_free": (C.c_int, [_P]),
@@ -111,6 +136,7 @@ SYMBOLS = {
     "rmd_event_create": (C.c_int, [C.POINTER(_P)]),
     "rmd_event_destroy": (C.c_int, [_P]),
     "rmd_event_record": (C.c_int, [_P, _P]),
+    "rmd_event_synchronize": (C.c_int, [_P]),
     "rmd_stream_wait_event": (C.c_int, [_P, _P]),
     "rmd_device_sync": (C.c_int, []),
     "rmd_device_count": (C.c_int, [C.POINTER(C.c_int)]),

@@ -34,7 +34,15 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 
 constexpr int kWave = 64;        // CDNA wavefront
 constexpr int kXcds = 8;         // MI355X accelerator complex dies (one L2 each)
-constexpr int kCus  = 256;
+constexpr int kCus  = 256;       // MI355X; device_cus() asks the current device
+constexpr int kMaxDevices = 16;
+
+// Facts and one-time setup that belong to a DEVICE, not to the process (a host program may drive
+// several GPUs from one process through rmd_set_device).
+int current_device();            // hipGetDevice, -1 on error
+int device_cus();                // multiProcessorCount of the current device (cached)
+// true exactly once per (device, key): guards per-device one-time calls such as hipFuncSetAttribute
+bool first_use_on_device(const void* key);
 
 // Plane geometry shared by the SVGF kernels: planes hold global rows
 // [buf_row0, buf_row0 + buf_rows) of a W x H frame.

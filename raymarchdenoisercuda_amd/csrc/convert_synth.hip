@@ -47,6 +47,19 @@ __global__ __launch_bounds__(256) void f32_to_u8_kernel(const float4* __restrict
     }
 }
 
+// Demodulation: SVGF filters ILLUMINATION = radiance / albedo, so texture detail is not
+// blurred; the albedo is multiplied back in rmd_convert_f32_to_u8.  One IEEE division per channel (the
+// oracle's operation), the denominator floored at eps so black albedo does not produce infinities.
+__global__ __launch_bounds__(256) void demodulate_kernel(const float4* __restrict__ radiance, const float4* __restrict__ albedo,
+                                                         float4* __restrict__ out, size_t n, float eps)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 c = radiance[i], al = albedo[i];
+        out[i] = make_float4(c.x / fmaxf(al.x, eps), c.y / fmaxf(al.y, eps), c.z / fmaxf(al.z, eps), c.w);
+    }
+}
+
 // ------------------------------------------------------------------------------ synthetic scene
 constexpr int kRegions = 64;
 struct Region {
@@ -190,6 +203,19 @@ int rmd_convert_f32_to_u8(const float* in, const float* albedo, rmd_uchar4* out,
     hipLaunchKernelGGL(f32_to_u8_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
                        (const float4*)in, (const float4*)albedo, (uchar4*)out, pixels);
     RMD_LAUNCH_CHECK("f32_to_u8_kernel");
+    return RMD_OK;
+}
+
+int rmd_demodulate(const float* radiance, const float* albedo, float* out, size_t pixels, float eps, void* stream)
+{
+    if (!radiance || !albedo || !out) return fail(RMD_E_NULL, "rmd_demodulate: NULL plane");
+    if (!aligned_to(radiance, 16) || !aligned_to(albedo, 16) || !aligned_to(out, 16)) return fail(RMD_E_ALIGN, "rmd_demodulate: misaligned plane");
+    if (!(eps > 0.0f)) return fail(RMD_E_PARAM, "rmd_demodulate: eps must be > 0");
+    if (pixels == 0) return RMD_OK;
+    const unsigned blocks = (unsigned)((pixels + 255) / 256 < 2048 ? (pixels + 255) / 256 : 2048);
+    hipLaunchKernelGGL(demodulate_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+                       (const float4*)radiance, (const float4*)albedo, (float4*)out, pixels, eps);
+    RMD_LAUNCH_CHECK("demodulate_kernel");
     return RMD_OK;
 }
 

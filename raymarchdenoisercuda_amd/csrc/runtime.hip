@@ -4,7 +4,10 @@
 // cudaDeviceSynchronize (src/test.cu:77,89) and printGPUProperties (src/utils.cpp:5-15).
 #include "common.h"
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 namespace rmd {
 
@@ -57,6 +60,41 @@ int check_rows_in_buffer(const rmd_svgf_frame_desc* f, int lo, int hi, const cha
 struct Timer {
     hipEvent_t start, stop;
 };
+
+int current_device()
+{
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+
+int device_cus()
+{
+    static int cus[kMaxDevices] = {};
+    const int d = current_device();
+    if (d < 0 || d >= kMaxDevices) return kCus;
+    if (cus[d] == 0) {
+        int n = 0;
+        cus[d] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : kCus;
+    }
+    return cus[d];
+}
+
+bool first_use_on_device(const void* key)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, unsigned>> seen;      // (key, bit mask of devices)
+    const int d = current_device();
+    const unsigned bit = 1u << ((d < 0 ? 0 : d) % 32);
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto& kv : seen)
+        if (kv.first == key) {
+            if (kv.second & bit) return false;
+            kv.second |= bit;
+            return true;
+        }
+    seen.emplace_back(key, bit);
+    return true;
+}
 
 }  // namespace rmd
 
@@ -174,6 +212,13 @@ int rmd_event_destroy(void* event)
 {
     if (!event) return RMD_OK;
     RMD_HIP(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return RMD_OK;
+}
+
+int rmd_event_synchronize(void* event)
+{
+    if (!event) return fail(RMD_E_NULL, "rmd_event_synchronize: event is NULL");
+    RMD_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
     return RMD_OK;
 }
 

@@ -1313,12 +1313,9 @@ template <int S>
 static int launch_pair(AtrousArgs a, hipStream_t stream)
 {
     using C = PairCfg<S>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (first_use_on_device(reinterpret_cast<const void*>(&atrous_pair_kernel<S>)))
         RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_pair_kernel<S>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_done = true;
-    }
     a.band_base = a.row0 / (4 * S) * (4 * S);
     const int rows = a.row1 - a.band_base;
     a.nstrips = (a.g.W + C::CW - 1) / C::CW;
@@ -1334,7 +1331,7 @@ static int launch_pair(AtrousArgs a, hipStream_t stream)
     // fills the rounds best, discounted by the 4 halo rows a workgroup stages on top of its own rows.
     // (3840 wide: 28 interior + 2 border strips = 32 S b workgroups, i.e. exactly 768 for S <= 8.)
     const int unit = S * C::ADV;
-    const int slots = C::WG_PER_CU * kCus;
+    const int slots = C::WG_PER_CU * device_cus();
     int best_nb = 1;
     double best = -1.0;
     for (int nb = 1; nb <= 64; ++nb) {
@@ -1380,12 +1377,11 @@ template <int S, int NP>
 static int launch_stream(AtrousArgs a, hipStream_t stream)
 {
     using C = StreamCfg<S, NP>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    // per device, not per process: a host that drives several GPUs through rmd_set_device needs the
+    // attribute (NP = 1 at step 16 asks for 65 568 bytes of LDS) on every one of them
+    if (first_use_on_device(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>)))
         RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        attr_done = true;
-    }
     // Bands are laid out from row0 rounded down to a multiple of 2S.  (They used to be aligned to
     // multiples of band_h in global rows: a strip that does not start on such a multiple then got one
     // band more than this heuristic planned, 780 workgroups for 768 slots, i.e. a second round --
@@ -1399,7 +1395,7 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
     // Number of bands: every workgroup does the same work, so the launch runs in
     // ceil(workgroups / resident slots) rounds; pick the band count that fills the rounds best,
     // discounted by the 4 halo rows each workgroup stages on top of its own lattice rows.
-    const int slots = C::WG_PER_CU * kCus;
+    const int slots = C::WG_PER_CU * device_cus();
     static const int min_rounds = [] { const char* e = getenv("RMD_ATROUS_MIN_ROUNDS"); return e ? atoi(e) : 1; }();
     int bh = ((rows + unit - 1) / unit) * unit;
     double best = -1.0;

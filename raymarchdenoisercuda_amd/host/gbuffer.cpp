@@ -9,7 +9,17 @@ CudaGBuffer::CudaGBuffer() : GBuffer{} {}
 
 CudaGBuffer::CudaGBuffer(int2 s) : GBuffer{} { allocate(s); }
 
-CudaGBuffer::~CudaGBuffer() { free(denoisedCPU); }
+CudaGBuffer::~CudaGBuffer()
+{
+    if (uploadDone) { rmd_event_synchronize(uploadDone); rmd_event_destroy(uploadDone); }
+    if (stage) rmd_host_free_pinned(stage);
+    free(denoisedCPU);
+}
+
+void CudaGBuffer::waitUpload()
+{
+    if (uploadDone) rmdCheck(rmd_event_synchronize(uploadDone), "CudaGBuffer::waitUpload");
+}
 
 void CudaGBuffer::allocate(int2 s)
 {
@@ -31,10 +41,22 @@ void CudaGBuffer::openImages(std::string filepath, void* stream)
         throw std::runtime_error("CudaGBuffer::openImages: planes in '" + filepath + "' differ in size");
     if (shape.x != r.shape.x || shape.y != r.shape.y) allocate(int2{ r.shape.x, r.shape.y });
     const size_t bytes = (size_t)shape.x * shape.y * 4;
-    rmdCheck(rmd_memcpy_h2d_async(render, r.data, bytes, stream), "openImages(render)");
-    rmdCheck(rmd_memcpy_h2d_async(albedo, a.data, bytes, stream), "openImages(albedo)");
-    rmdCheck(rmd_memcpy_h2d_async(normal, n.data, bytes, stream), "openImages(normal)");
-    rmdCheck(rmd_stream_sync(stream), "openImages(sync)");   // the Images die at scope exit
+    waitUpload();                                             // the staging buffer may still feed the previous upload
+    if (stageBytes < 3 * bytes) {
+        if (stage) rmd_host_free_pinned(stage);
+        stage = nullptr; stageBytes = 0;
+        rmdCheck(rmd_host_alloc_pinned((void**)&stage, 3 * bytes), "openImages(pinned staging)");
+        stageBytes = 3 * bytes;
+    }
+    if (!uploadDone) rmdCheck(rmd_event_create(&uploadDone), "openImages(event)");
+    // decoded pixels -> pinned staging (the Images die at scope exit, the staging lives with the object)
+    memcpy(stage, r.data, bytes);
+    memcpy(stage + bytes, a.data, bytes);
+    memcpy(stage + 2 * bytes, n.data, bytes);
+    rmdCheck(rmd_memcpy_h2d_async(render, stage, bytes, stream), "openImages(render)");
+    rmdCheck(rmd_memcpy_h2d_async(albedo, stage + bytes, bytes, stream), "openImages(albedo)");
+    rmdCheck(rmd_memcpy_h2d_async(normal, stage + 2 * bytes, bytes, stream), "openImages(normal)");
+    rmdCheck(rmd_event_record(uploadDone, stream), "openImages(record)");      // no blocking sync here
 }
 
 uchar4* CudaGBuffer::download()

@@ -20,6 +20,7 @@
 
 #include "filter.h"
 #include "svgf.h"
+#include "strips.h"
 
 static std::string dataPath()   // render/<scene>/<frame>/ layout of the reference (render/cornell/1/)
 {
@@ -228,14 +229,18 @@ TEST(SVGF_CORNELL)
     const int W = g.shape.x, H = g.shape.y;
     const size_t n = (size_t)W * H;
     CudaVector<float> color(4 * n), nd(4 * n), albedo(4 * n), motion(2 * n), out(4 * n);
+    // everything below is queued behind the asynchronous upload of openImages on the same (default) stream
     rmdCheck(rmd_convert_u8_to_f32((rmd_uchar4*)g.render, color.data(), n, 0, 0.0f, nullptr), "convert render");
+    rmdCheck(rmd_convert_u8_to_f32((rmd_uchar4*)g.albedo, albedo.data(), n, 0, 0.0f, nullptr), "convert albedo");
     rmdCheck(rmd_convert_u8_to_f32((rmd_uchar4*)g.normal, nd.data(), n, 1, 1.0f, nullptr), "convert normal");
+    // SVGF filters illumination = radiance / albedo; the albedo comes back when the result is quantised
+    rmdCheck(rmd_demodulate(color.data(), albedo.data(), color.data(), n, 1.0f / 255.0f, nullptr), "demodulate");
     motion.fill(0);
     SvgfContext ctx(W, H);
     const SvgfParams p = svgfDefaultParams();
     for (int f = 0; f < 3; ++f)                          // static camera: history accumulates
         ctx.denoise(p, color.data(), nd.data(), motion.data(), f ? nd.data() : nullptr, out.data(), 0, H);
-    rmdCheck(rmd_convert_f32_to_u8(out.data(), nullptr, (rmd_uchar4*)g.denoised, n, nullptr), "convert denoised");
+    rmdCheck(rmd_convert_f32_to_u8(out.data(), albedo.data(), (rmd_uchar4*)g.denoised, n, nullptr), "modulate + convert denoised");
     uchar4* host = g.download();
     CpuVector<uchar4> noisy;
     g.renderVec.copyTo(noisy);
@@ -253,6 +258,108 @@ TEST(SVGF_CORNELL)
     expect(roughOut < 0.5 * roughIn, "denoising removes at least half of the pixel-to-pixel noise");
     ensureOutputDir();
     Image::save(OUTPUT_PATH + "cornell_svgf.png", (byte*)host, int3{ W, H, 4 });
+}
+
+// ---- CudaVector: the semantics of the reference's container (include/vector.h:119-169) ---------
+TEST(VECTOR)
+{
+    CpuVector<int> host(1000);
+    for (int i = 0; i < 1000; ++i) host[i] = 7 * i + 1;
+    CudaVector<int> fromPtr(host.data(), host.size());          // allocates and copies from the HOST pointer (:124-127)
+    CudaVector<int> fromVec(host);                              // :130
+    CpuVector<int> back;
+    fromPtr.copyTo(back);
+    expect(back == host, "CudaVector(T*, n) holds a device copy of the host data");
+    fromVec.copyTo(back);
+    expect(back == host, "CudaVector(CpuVector&) holds a device copy");
+    CudaVector<int> big(2000);
+    big.fill(0);
+    big.copyFrom(host.data(), host.size());                     // n <= size is accepted (:142-146)
+    big.copyTo(back);
+    expect(back.size() == 2000 && std::equal(host.begin(), host.end(), back.begin()) && back[1500] == 0, "copyFrom(T*, n <= size)");
+    bool threw = false;
+    try { fromPtr.copyFrom(host.data(), 1001); } catch (const std::runtime_error&) { threw = true; }
+    expect(threw, "copyFrom beyond the size throws std::runtime_error");
+    {
+        CudaVector<int> view = CudaVector<int>::wrap(fromPtr.data(), 10);    // non-owning view of device memory
+        CpuVector<int> ten;
+        view.copyTo(ten);
+        expect(ten.size() == 10 && ten[9] == host[9], "wrap() views device memory");
+    }
+    fromPtr.copyTo(back);                                       // still alive after the view is gone
+    expect(back == host, "wrap() does not free");
+}
+
+// ---- row strips: one frame cut over several ranks gives the bits of the unsharded frame ----
+// Ranks are spread over the visible GPUs (RCCL neighbour exchange between distinct devices, device-to-device
+// copies by the same plan between ranks that share one); with one GPU this rehearses plan, contexts and
+// ordering of the C++ multi-GPU path.
+TEST(SVGF_STRIPS)
+{
+    const int W = 256, H = 600, frames = 3;
+    const size_t n = (size_t)W * H;
+    SvgfParams p = svgfDefaultParams();
+    p.max_motion_rows = 8;
+    int ndev = 1;
+    rmdCheck(rmd_device_count(&ndev), "device count");
+    const int world = 3;
+    std::vector<int> devices(world);
+    for (int k = 0; k < world; ++k) devices[k] = ndev >= world ? k : 0;
+    printf("%d ranks on %d visible device(s)%s\n", world, ndev, ndev >= world ? " (RCCL exchange)" : " (shared device: plan-driven copies)");
+
+    // reference: the unsharded frame on device 0
+    rmdCheck(rmd_set_device(0), "set device");
+    std::vector<CpuVector<float>> want(frames);
+    {
+        std::vector<CudaVector<float>> color, nd, motion;
+        CudaVector<float> out(4 * n);
+        SvgfContext ctx(W, H);
+        for (int f = 0; f < frames; ++f) {
+            color.emplace_back(4 * n); nd.emplace_back(4 * n); motion.emplace_back(2 * n);
+            rmd_synth_desc d = { W, H, 0, H, 1234u, f, 1.25f, -0.5f };
+            rmdCheck(rmd_synth_gbuffer(&d, color[f].data(), nd[f].data(), motion[f].data(), nullptr, nullptr), "synth");
+            ctx.denoise(p, color[f].data(), nd[f].data(), motion[f].data(), f ? nd[f - 1].data() : nullptr, out.data(), 0, H);
+            out.copyTo(want[f]);
+        }
+    }
+    NodeDenoiser node(W, H, p, devices);
+    std::vector<std::vector<CudaVector<float>>> color(world), nd(world), motion(world);
+    std::vector<CudaVector<float>> out;
+    for (int k = 0; k < world; ++k) {
+        const StripPlan& pl = node.ranks[k].plan;
+        rmdCheck(rmd_set_device(devices[k]), "set device");
+        const size_t m = (size_t)W * pl.buf_rows;
+        out.emplace_back(4 * m);
+        for (int f = 0; f < frames; ++f) {
+            color[k].emplace_back(4 * m); nd[k].emplace_back(4 * m); motion[k].emplace_back(2 * m);
+            rmd_synth_desc d = { W, H, pl.buf_row0, pl.buf_rows, 1234u, f, 1.25f, -0.5f };
+            rmdCheck(rmd_synth_gbuffer(&d, color[k][f].data(), nd[k][f].data(), motion[k][f].data(), nullptr, nullptr), "synth strip");
+        }
+        expect(pl.haloSteps().size() == (k == 0 || k == world - 1 ? 4u : 8u), "a border rank exchanges with one neighbour, an inner rank with two");
+    }
+    rmdCheck(rmd_device_sync(), "sync");
+    size_t differing = 0;
+    for (int f = 0; f < frames; ++f) {
+        std::vector<const float*> c(world), g(world), m(world), pn(world);
+        std::vector<float*> o(world);
+        for (int k = 0; k < world; ++k) {
+            c[k] = color[k][f].data(); g[k] = nd[k][f].data(); m[k] = motion[k][f].data();
+            pn[k] = f ? nd[k][f - 1].data() : nullptr; o[k] = out[k].data();
+        }
+        node.denoise(c, g, m, pn, o);
+        node.synchronize();
+        for (int k = 0; k < world; ++k) {
+            const StripPlan& pl = node.ranks[k].plan;
+            rmdCheck(rmd_set_device(devices[k]), "set device");
+            CpuVector<float> got;
+            out[k].copyTo(got);
+            for (int y = pl.row0; y < pl.row1; ++y)
+                differing += memcmp(&got[(size_t)(y - pl.buf_row0) * W * 4], &want[f][(size_t)y * W * 4], (size_t)W * 16) != 0;
+        }
+    }
+    rmdCheck(rmd_set_device(0), "set device");
+    printf("%d frames x %d strips: %zu rows differ from the unsharded frame\n", frames, world, differing);
+    expect(differing == 0, "row strips reproduce the unsharded frame bit for bit");
 }
 
 // ---- full SVGF at 4K on the synthetic scene (BASELINE config 3), timed with HIP events -------

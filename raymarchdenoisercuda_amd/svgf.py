@@ -120,6 +120,14 @@ def convert_f32_to_u8(src_f32, albedo=None, stream=None):
     return out
 
 
+def demodulate(radiance, albedo, eps=1e-3, out=None, stream=None):
+    """illumination = radiance / max(albedo, eps) per rgb channel, w passed through (rmd_demodulate)."""
+    out = torch.empty_like(radiance) if out is None else out
+    check(lib.rmd_demodulate(radiance.data_ptr(), albedo.data_ptr(), out.data_ptr(), radiance.shape[0] * radiance.shape[1],
+                             float(eps), _stream_ptr(stream)))
+    return out
+
+
 class SvgfDenoiser:
     """Cross-frame SVGF state for one device / one row strip.
 

@@ -46,6 +46,8 @@ def _load():
     lib.orc_hash32.restype = C.c_uint32
     lib.orc_convert_u8_to_f32.argtypes = [P, P, C.c_size_t, C.c_int, C.c_float]
     lib.orc_convert_f32_to_u8.argtypes = [P, P, P, C.c_size_t]
+    lib.orc_demodulate.argtypes = [P, P, P, C.c_size_t, C.c_float]
+    lib.orc_demodulate.restype = None
     lib.orc_hardware_threads.restype = C.c_int
     for f in (lib.orc_box_level, lib.orc_box_filter, lib.orc_box_filter_mt, lib.orc_svgf_temporal, lib.orc_svgf_variance,
               lib.orc_svgf_atrous, lib.orc_svgf_frame, lib.orc_svgf_pass_mt, lib.orc_synth_gbuffer,
@@ -168,6 +170,14 @@ def convert_f32_to_u8(src_f32, albedo=None):
     alb = None if albedo is None else np.ascontiguousarray(albedo, np.float32)
     out = np.zeros(src.shape, np.uint8)
     lib.orc_convert_f32_to_u8(_p(src), _p(alb), _p(out), src.shape[0] * src.shape[1])
+    return out
+
+
+def demodulate(radiance, albedo, eps=1e-3):
+    r = np.ascontiguousarray(radiance, np.float32)
+    a = np.ascontiguousarray(albedo, np.float32)
+    out = np.zeros(r.shape, np.float32)
+    lib.orc_demodulate(_p(r), _p(a), _p(out), r.shape[0] * r.shape[1], eps)
     return out
 
 

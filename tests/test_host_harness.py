@@ -1,0 +1,69 @@
+"""The C++ host harness (raymarchdenoisercuda_amd/host, the reference's `main -t [label]` over the C ABI) under
+pytest: on the GPU box every registered test body must print `Passed with`; here (no GPU) the PNG codec test
+runs, and -- in the build container only, where /root/reference exists -- the reference's own unmodified
+src/main.cpp is compiled against include/ and linked with librmd.so + the harness's test.cpp (drop-in check)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MAIN = os.path.join(ROOT, "build", "main")
+REFERENCE = "/root/reference"
+
+
+def ensure_harness():
+    if not os.path.exists(MAIN):
+        subprocess.run(["make", "-C", ROOT, "host"], check=True, capture_output=True, timeout=600)
+    return MAIN
+
+
+def run_tests(*labels):
+    argv = [ensure_harness()]
+    for l in labels:
+        argv += ["-t", l]
+    if not labels:
+        argv.append("-t")                   # `main -t`: every registered test (reference Makefile:61-62)
+    return subprocess.run(argv, cwd=ROOT, capture_output=True, text=True, timeout=900)
+
+
+def test_cli_contract_of_the_reference_main():
+    r = subprocess.run([ensure_harness(), "-h"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "-t [label]" in r.stdout           # reference src/main.cpp:5-10,31-33
+    r = subprocess.run([ensure_harness()], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Usage" in r.stdout                # no arguments = help (src/main.cpp:13-16)
+
+
+def test_png_round_trip_runs_without_a_gpu():
+    r = run_tests("IMAGE")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("Passed with") == 1 and "Fail" not in r.stdout
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="the reference tree only exists in the build container")
+def test_reference_main_cpp_compiles_against_our_headers(tmp_path):
+    """Drop-in check: the reference's UNMODIFIED src/main.cpp (it includes "test.h" and calls test(label))
+    builds against include/ and links with the harness's test registry and librmd.so."""
+    exe = tmp_path / "ref_main"
+    host = os.path.join(ROOT, "raymarchdenoisercuda_amd", "host")
+    srcs = [os.path.join(REFERENCE, "src", "main.cpp")] + [os.path.join(host, f) for f in sorted(os.listdir(host))
+                                                          if f.endswith(".cpp") and f != "main.cpp"]
+    cmd = ["g++", "-O1", "-std=c++17", "-w", f"-I{ROOT}/include", "-I/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-o", str(exe),
+           *srcs, f"-L{ROOT}/raymarchdenoisercuda_amd/lib", "-lrmd", "-lz", f"-Wl,-rpath,{ROOT}/raymarchdenoisercuda_amd/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    h = subprocess.run([str(exe), "-h"], capture_output=True, text=True, timeout=60)
+    assert "Usage" in h.stdout
+
+
+@pytest.mark.gpu
+def test_every_harness_test_passes_on_the_gpu():
+    """DEVICE_STATS, FILTER_BASELINE, FILTER_TILED, FILTER_CORNELL (SHA-256 known answers through
+    filterKernelBaseline / filterKernelTiled), IMAGE, VECTOR, SVGF_CORNELL (openImages upload, demodulation),
+    SVGF_STRIPS (C++ multi-rank path) and SVGF_4K."""
+    r = run_tests()
+    sys.stdout.write(r.stdout[-6000:])
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "Fail" not in r.stdout
+    assert r.stdout.count("Passed with") >= 9

@@ -1,0 +1,101 @@
+"""The C-ABI row-strip planner (rmd_strip_plan_make / rmd_halo_plan / rmd_halo_bytes, csrc/strips.hip) against
+the Python one the torch.distributed path uses (raymarchdenoisercuda_amd/sharding.py): same strips, same
+buffers, same halo steps in the same order.  Pure arithmetic, no GPU.  The RCCL exchange itself is
+exercised on the GPU box (loop-back on one device)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from raymarchdenoisercuda_amd import sharding
+from raymarchdenoisercuda_amd._lib import HaloStep, StripPlan, lib
+
+
+def c_plan(rmd, height, world, rank, p):
+    plan = StripPlan()
+    rmd.check(lib.rmd_strip_plan_make(height, world, rank, C.byref(p), C.byref(plan)))
+    return plan
+
+
+def c_steps(rmd, plan):
+    steps = (HaloStep * 8)()
+    n = C.c_int()
+    rmd.check(lib.rmd_halo_plan(C.byref(plan), steps, 8, C.byref(n)))
+    kind = {HaloStep.RECV: "recv", HaloStep.SEND: "send"}
+    name = {0: "color", 1: "moments"}
+    return [(kind[s.kind], name[s.plane], s.row_lo, s.row_hi, s.peer) for s in steps[:n.value]]
+
+
+@pytest.mark.parametrize("height,world", [(4320, 8), (4320, 4), (4320, 2), (2160, 4), (1000, 3), (420, 2), (300, 1), (4321, 8)])
+def test_c_planner_equals_python_planner(rmd, height, world):
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    reach = rmd.svgf.frame_reach(p)
+    for rank in range(world):
+        want = sharding.make_plan(height, world, rank, reach)
+        got = c_plan(rmd, height, world, rank, p)
+        for f in ("height", "world", "rank", "row0", "row1", "buf_row0", "buf_rows", "reach_in", "reach_hist", "have_color", "have_moments"):
+            assert getattr(got, f) == getattr(want, f), (rank, f)
+        assert c_steps(rmd, got) == sharding.halo_plan(want), rank
+        assert lib.rmd_halo_bytes(C.byref(got), 7680) == sharding.halo_bytes(want, 7680)
+        r0, r1 = C.c_int(), C.c_int()
+        rmd.check(lib.rmd_strip_rows(height, world, rank, C.byref(r0), C.byref(r1)))
+        assert (r0.value, r1.value) == sharding.strip_rows(height, world, rank)
+
+
+def test_other_parameters_change_the_plan_the_same_way(rmd):
+    p = rmd.default_params()
+    p.max_motion_rows, p.iterations, p.hist_iteration = 2, 3, 2
+    reach = rmd.svgf.frame_reach(p)
+    for rank in range(4):
+        want = sharding.make_plan(2160, 4, rank, reach)
+        got = c_plan(rmd, 2160, 4, rank, p)
+        assert c_steps(rmd, got) == sharding.halo_plan(want)
+        assert (got.buf_row0, got.buf_rows) == (want.buf_row0, want.buf_rows)
+
+
+def test_short_strips_and_bad_arguments_are_rejected(rmd):
+    p = rmd.default_params()
+    plan = StripPlan()
+    assert lib.rmd_strip_plan_make(400, 8, 0, C.byref(p), C.byref(plan)) == -5          # RMD_E_ROWS, like sharding.make_plan
+    with pytest.raises(ValueError):
+        sharding.make_plan(400, 8, 0, rmd.svgf.frame_reach(p))
+    assert lib.rmd_strip_plan_make(4320, 8, 8, C.byref(p), C.byref(plan)) == -3          # rank outside the world
+    assert lib.rmd_strip_plan_make(4320, 8, 0, None, C.byref(plan)) == -1
+    n = C.c_int()
+    rmd.check(lib.rmd_strip_plan_make(4320, 8, 3, C.byref(p), C.byref(plan)))
+    rmd.check(lib.rmd_halo_plan(C.byref(plan), None, 0, C.byref(n)))                      # counting form
+    assert n.value == 8
+    steps = (HaloStep * 2)()
+    assert lib.rmd_halo_plan(C.byref(plan), steps, 2, C.byref(n)) == -4 and n.value == 8  # RMD_E_BUFFER, count still reported
+
+
+def test_exchange_without_neighbours_needs_no_communicator(rmd):
+    p = rmd.default_params()
+    plan = c_plan(rmd, 300, 1, 0, p)
+    rmd.check(lib.rmd_halo_exchange(None, C.byref(plan), 64, None, None, None))
+
+
+@pytest.mark.gpu
+def test_rccl_loopback_exchange_on_one_gpu(rmd, cuda):
+    """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd through the C ABI with a one-rank communicator:
+    rows [10,14) of hist_color are sent to self into rows [20,24), rows [3,5) of hist_moments into [30,32)."""
+    assert lib.rmd_comm_available() == 1, "librccl.so not found on the GPU box"
+    comm = C.c_void_p()
+    rmd.check(lib.rmd_comm_create_all(1, None, C.byref(comm)))
+    width, rows = 96, 40
+    g = torch.Generator(device="cuda").manual_seed(5)
+    hc = torch.rand((rows, width, 4), device="cuda", generator=g)
+    hm = torch.rand((rows, width, 4), device="cuda", generator=g)
+    want_c, want_m = hc.clone(), hm.clone()
+    want_c[20:24] = hc[10:14]
+    want_m[30:32] = hm[3:5]
+    steps = (HaloStep * 4)(HaloStep(HaloStep.RECV, 0, 120, 124, 0), HaloStep(HaloStep.SEND, 0, 110, 114, 0),
+                           HaloStep(HaloStep.RECV, 1, 130, 132, 0), HaloStep(HaloStep.SEND, 1, 103, 105, 0))
+    stream = torch.cuda.current_stream().cuda_stream
+    rmd.check(lib.rmd_halo_exchange_steps(comm, 0, steps, 4, 100, rows, width, hc.data_ptr(), hm.data_ptr(), stream))
+    torch.cuda.synchronize()
+    assert torch.equal(hc, want_c) and torch.equal(hm, want_m)
+    bad = (HaloStep * 1)(HaloStep(HaloStep.SEND, 0, 90, 95, 0))
+    assert lib.rmd_halo_exchange_steps(comm, 0, bad, 1, 100, rows, width, hc.data_ptr(), hm.data_ptr(), stream) == -5
+    rmd.check(lib.rmd_comm_destroy(comm))
