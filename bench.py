@@ -191,6 +191,53 @@ def other_size(rmd, torch, width, height, p, frames=16, warm=4):
             "moved_GBps": round(MOVED_BYTES_PER_PX * width * height * frames / dt / 1e9, 1), "frames": frames}
 
 
+def cornell_sequence(rmd, torch, p, width=3840, height=2160, frames=60, warm=6, pan=(2, 1)):
+    """BASELINE configs[4]: a 60-frame 4K animated Cornell sequence, steady-state frames per second.
+    The 500x500 Cornell planes (tests/golden/cornell, the reference's render/cornell/1 fixtures) are tiled to
+    the frame, the camera pans `pan` pixels per frame (the tiled image is periodic, so a roll IS the pan;
+    motion = -pan, current -> previous), per-frame re-seeded noise multiplies the radiance, illumination =
+    radiance / albedo (rmd_demodulate).  All frames are resident before the clock starts."""
+    import numpy as np
+    from PIL import Image
+    gold = os.path.join(ROOT, "tests", "golden", "cornell")
+
+    def plane(name):
+        rgb = np.array(Image.open(os.path.join(gold, f"{name}.png")).convert("RGB"))
+        rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
+        return torch.from_numpy(np.ascontiguousarray(rgba)).cuda()
+
+    render = rmd.svgf.convert_u8_to_f32(plane("render"), False, 0.0)
+    albedo = rmd.svgf.convert_u8_to_f32(plane("albedo"), False, 0.0)
+    normal = rmd.svgf.convert_u8_to_f32(plane("normal"), True, 1.0)        # unit or zero normals, depth plane = 1 (saturated in the fixture)
+    reps = (-(-height // render.shape[0]), -(-width // render.shape[1]), 1)
+    tile = lambda t: t.repeat(*reps)[:height, :width].contiguous()          # noqa: E731
+    radiance, albedo, nd0 = tile(render), tile(albedo), tile(normal)
+    illum = rmd.svgf.demodulate(radiance, albedo, 1.0 / 255.0)
+    motion = torch.empty((height, width, 2), dtype=torch.float32, device="cuda")
+    motion[..., 0], motion[..., 1] = -float(pan[0]), -float(pan[1])
+    g = torch.Generator(device="cuda").manual_seed(2024)
+    seq = []
+    for f in range(warm + frames):
+        c = torch.roll(illum, shifts=(f * pan[1], f * pan[0]), dims=(0, 1)).contiguous()
+        c[..., :3] *= (0.75 + 0.5 * torch.rand((height, width, 1), device="cuda", generator=g))
+        seq.append((c, torch.roll(nd0, shifts=(f * pan[1], f * pan[0]), dims=(0, 1)).contiguous()))
+    den = rmd.SvgfDenoiser(width, height, params=p)
+    out = torch.empty_like(seq[0][0])
+    for f in range(warm):
+        den.denoise(seq[f][0], seq[f][1], motion, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(warm, warm + frames):
+        den.denoise(seq[f][0], seq[f][1], motion, out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    u8 = rmd.svgf.convert_f32_to_u8(out, albedo)                              # modulate + quantise the last frame (not timed)
+    return {"workload": f"{frames}-frame {width}x{height} animated Cornell sequence (tiled fixture planes, pan {pan} px/frame, "
+                        "re-seeded noise, demodulated by albedo), full SVGF fp32, inputs resident",
+            "frames": frames, "fps": round(frames / dt, 1), "ms_per_frame": round(dt / frames * 1e3, 4),
+            "mpix_s": round(width * height * frames / dt / 1e6, 1), "last_frame_mean_u8": round(float(u8[..., :3].float().mean()), 2)}
+
+
 def reference_api_kernels(rmd, torch, width=3840, height=2160):
     """The reference's own entry points (uchar4 box mean, radius 2, depth 1: src/test.cu:68-90) on a 4K
     plane: microseconds per launch and algorithmic GB/s (8 B/px).  Not the headline value."""
@@ -383,6 +430,7 @@ def main():
         result["other_sizes"] = {f"{w}x{h}": other_size(rmd, torch, w, h, p, frames=n, warm=wu)
                                  for w, h, n, wu in ((1920, 1080, 48, 8), (7680, 4320, 16, 4))}
         result["reference_api"] = reference_api_kernels(rmd, torch)
+        result["cornell_sequence_4k"] = cornell_sequence(rmd, torch, p)       # BASELINE configs[4]
     if world > 1 and rank == 0 and not args.no_other_sizes:
         # the SAME 8K frame unsharded on rank 0's GPU: what the N-GPU figure is a speed-up over
         del frames, sd

@@ -331,7 +331,7 @@ struct StreamCfg {
     static constexpr int LDS_BYTES = VAR_OFF + 4 * NP * VAR_ROW * 4;
     static constexpr int TAIL = 16 * S * NP;          // float4 elements in the 4S-pixel row tails of one refill
     static constexpr int NT = (TAIL + 255) / 256;     // tail loads per thread
-    static constexpr int WG_PER_CU = NP == 1 ? 2 : 3;
+    static constexpr int WG_PER_CU = NP == 1 ? 2 : 3;      // LDS-limited (NP = 4: 3 as well, by registers)
 };
 
 __device__ __forceinline__ float4 lds_f4(const unsigned char* lds, int off) { return *reinterpret_cast<const float4*>(lds + off); }
@@ -379,11 +379,15 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     // jb+2pr, jb+2pr+1 of both planes; the 4S-pixel tails of the ADV rows x 2 planes (TAIL float4
     // in all) are spread over the threads: tail element e -> row (e/4S)>>1, plane (e/4S)&1,
     // column CW + e%4S.
-    auto load_rows = [&](const int jb) {
+    // (NROWS < ADV: only the first NROWS rows of the refill are fetched -- the prologue of the NP = 4 ring, whose
+    // 12 rows are one and a half refills; the rows beyond may lie outside the buffer)
+    auto load_rows_n = [&](const int jb, auto nrows_c) {
+        constexpr int NROWS = decltype(nrows_c)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int y = ybase + (jb + 2 * pr + i) * S;
             bool act = !EDGE || (row_in_buffer(y) && x - 2 * S >= 0 && x - 2 * S < g.W);
+            if (NROWS < C::ADV) act = act && 2 * pr + i < NROWS;
             float4 vc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), vn = vc;
             if (act) {
                 const long long o = row_base(y, x0 - 2 * S);
@@ -400,6 +404,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             const int y = ybase + (jb + (sel >> 1)) * S;
             const int gx = x0 - 2 * S + C::CW + e % (4 * S);
             bool act = e < C::TAIL;
+            if (NROWS < C::ADV) act = act && (sel >> 1) < NROWS;
             if (EDGE) act = act && row_in_buffer(y) && gx >= 0 && gx < g.W;
             float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if (act) {
@@ -409,10 +414,14 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             pe[q] = v;
         }
     };
+    auto load_rows = [&](const int jb) { load_rows_n(jb, std::integral_constant<int, C::ADV>{}); };
     // colour is staged as (lum, r, g, var): luminance once per staged pixel instead of once per tap
-    auto store_rows = [&](const int jb) {
+    // (nrows < ADV: only the first nrows rows of the refill are stored -- the prologue of the NP = 4 ring,
+    // whose 12 rows are one and a half refills)
+    auto store_rows = [&](const int jb, const int nrows = C::ADV) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (2 * pr + i >= nrows) continue;
             const int off = slot_of(jb + 2 * pr + i) * C::ROW_BYTES + col * 16;
             *reinterpret_cast<float4*>(lds + off) = to_lrgv(pc[i]);
             *reinterpret_cast<float4*>(lds + C::PLANE_BYTES + off) = pn[i];
@@ -422,6 +431,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             const int e = tid + q * 256;
             if (e < C::TAIL) {
                 const int sel = e / (4 * S);
+                if ((sel >> 1) >= nrows) continue;
                 const bool is_nd = (sel & 1) != 0;
                 const int off = (is_nd ? C::PLANE_BYTES : 0) + slot_of(jb + (sel >> 1)) * C::ROW_BYTES + (C::CW + e % (4 * S)) * 16;
                 *reinterpret_cast<float4*>(lds + off) = is_nd ? pe[q] : to_lrgv(pe[q]);
@@ -605,11 +615,17 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
 
     // ---- prologue: ring rows j0-2 .. j0-2+NR-1 (NR/ADV refills) and the aux rows of the first step
     const int j0 = jlo & ~1;
+    constexpr int kFull = C::NR / C::ADV, kRest = C::NR % C::ADV;
 #pragma unroll
-    for (int q = 0; q < C::NR / C::ADV; ++q) {
+    for (int q = 0; q < kFull; ++q) {
         load_rows(j0 - 2 + q * C::ADV);
-        if (q == C::NR / C::ADV - 1) load_aux(j0);
+        if (kRest == 0 && q == kFull - 1) load_aux(j0);
         store_rows(j0 - 2 + q * C::ADV);
+    }
+    if (kRest != 0) {
+        load_rows_n(j0 - 2 + kFull * C::ADV, std::integral_constant<int, (kRest ? kRest : C::ADV)>{});
+        load_aux(j0);
+        store_rows(j0 - 2 + kFull * C::ADV, kRest);
     }
     store_aux();
     __syncthreads();
@@ -1373,15 +1389,12 @@ static int launch_pair_iter(int iteration, const AtrousArgs& a, hipStream_t stre
     }
 }
 
+// Work decomposition of one stream launch: fills the band fields of `a`, returns the efficiency estimate
+// (share of the resident workgroup slots used by whole rounds) x (own lattice rows / staged lattice rows).
 template <int S, int NP>
-static int launch_stream(AtrousArgs a, hipStream_t stream)
+static double plan_stream(AtrousArgs& a)
 {
     using C = StreamCfg<S, NP>;
-    // per device, not per process: a host that drives several GPUs through rmd_set_device needs the
-    // attribute (NP = 1 at step 16 asks for 65 568 bytes of LDS) on every one of them
-    if (first_use_on_device(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>)))
-        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     // Bands are laid out from row0 rounded down to a multiple of 2S.  (They used to be aligned to
     // multiples of band_h in global rows: a strip that does not start on such a multiple then got one
     // band more than this heuristic planned, 780 workgroups for 768 slots, i.e. a second round --
@@ -1389,7 +1402,7 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
     a.band_base = a.row0 / (2 * S) * (2 * S);
     const int rows = a.row1 - a.band_base;
     a.nstrips = (a.g.W + C::CW - 1) / C::CW;
-    // one resident wave of workgroups: WG_PER_CU per CU (LDS-limited) x 256 CUs
+    // one resident wave of workgroups: WG_PER_CU per CU (LDS-limited) x the CUs of the device
     const int per_band = a.nstrips * S;
     const int unit = S * C::ADV;                        // whole steps per lattice
     // Number of bands: every workgroup does the same work, so the launch runs in
@@ -1415,9 +1428,44 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
     const int nbands = (rows + bh - 1) / bh;
     a.nblocks = nbands * per_band;
     a.per_xcd = (a.nblocks + kXcds - 1) / kXcds;
+    return best;
+}
+
+template <int S, int NP>
+static int launch_planned(const AtrousArgs& a, hipStream_t stream)
+{
+    using C = StreamCfg<S, NP>;
+    // per device, not per process: a host that drives several GPUs through rmd_set_device needs the
+    // attribute (NP = 1 at step 16 asks for 65 568 bytes of LDS) on every one of them
+    if (first_use_on_device(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>)))
+        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S, NP>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES, stream, a);
     RMD_LAUNCH_CHECK("atrous_stream_kernel");
     return RMD_OK;
+}
+
+template <int S, int NP>
+static int launch_stream(AtrousArgs a, hipStream_t stream)
+{
+    plan_stream<S, NP>(a);
+    return launch_planned<S, NP>(a, stream);
+}
+
+// Library default: 128-column strips with two row pairs per step (NP = 2), unless 64-column strips with four
+// (NP = 4, bands of 8S rows, (64 + 4S) staged columns per 64) decompose the frame clearly better.  At equal
+// decomposition efficiency the two run at the same speed (bench.py, 4K: 125 / 131 / 132 / 133 / 140 us against
+// 127 / 132 / 131 / 139 / 142 us per iteration); at step 16 the staged strips would be twice their width: never.
+template <int S>
+static int launch_stream_auto(AtrousArgs a, hipStream_t stream)
+{
+    constexpr double kGain4 = S <= 8 ? 0.95 : 0.0;
+    static const int force = [] { const char* e = getenv("RMD_ATROUS_NP"); return e ? atoi(e) : 0; }();
+    AtrousArgs a2 = a, a4 = a;
+    const double e2 = plan_stream<S, 2>(a2);
+    const double e4 = kGain4 > 0.0 ? plan_stream<S, 4>(a4) * kGain4 : 0.0;
+    const bool four = force == 4 ? kGain4 > 0.0 : (force == 2 ? false : e4 > e2);
+    return four ? launch_planned<S, 4>(a4, stream) : launch_planned<S, 2>(a2, stream);
 }
 
 template <int NP>
@@ -1429,6 +1477,17 @@ static int launch_stream_iter(int iteration, const AtrousArgs& a, hipStream_t st
         case 2: return launch_stream<4, NP>(a, stream);
         case 3: return launch_stream<8, NP>(a, stream);
         default: return launch_stream<16, NP>(a, stream);
+    }
+}
+
+static int launch_stream_auto_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
+{
+    switch (iteration) {
+        case 0: return launch_stream_auto<1>(a, stream);
+        case 1: return launch_stream_auto<2>(a, stream);
+        case 2: return launch_stream_auto<4>(a, stream);
+        case 3: return launch_stream_auto<8>(a, stream);
+        default: return launch_stream_auto<16>(a, stream);
     }
 }
 
@@ -1461,7 +1520,10 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     a.n_int = a.xe_lo = a.band_h_xe = a.total_int = a.int_per_xcd = a.xe_per_xcd = 0;
 
     int variant = p->atrous_variant;
-    if (variant == 0) variant = (iteration <= 4) ? 3 : 1;
+    if (variant == 0) {
+        if (iteration <= 4) return launch_stream_auto_iter(iteration, a, as_stream(stream));
+        variant = 1;
+    }
     if ((variant == 2 || variant == 3) && iteration > 4)
         return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
     if (variant == 4) {
@@ -1473,6 +1535,10 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
         hipLaunchKernelGGL(atrous_direct2_kernel, grid5, dim3(256), 0, as_stream(stream), a);
         RMD_LAUNCH_CHECK("atrous_direct2_kernel");
         return RMD_OK;
+    }
+    if (variant == 6) {                                                               // 64 columns x 4 row pairs
+        if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
+        return launch_stream_iter<4>(iteration, a, as_stream(stream));
     }
     if (variant == 2) return launch_stream_iter<1>(iteration, a, as_stream(stream));   // 256 columns x 1 row pair
     if (variant == 3) return launch_stream_iter<2>(iteration, a, as_stream(stream));   // 128 columns x 2 row pairs

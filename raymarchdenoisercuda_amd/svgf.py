@@ -213,7 +213,8 @@ class SvgfDenoiser:
     def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None):
         """One frame.  `nd` is borrowed until the next call (it becomes prev_nd).  `before_tv` is
         called just before T is launched, on the stream T runs on (a row-strip deployment completes
-        its history halo there)."""
+        its history halo there).  Serial form: runs on `stream` (default: torch's current stream).
+        Pipelined form: runs on two side streams; the inputs must stay untouched until synchronize()."""
         if out is None:
             out = torch.empty_like(color)
         row0 = max(self.buf_row0, 0) if row0 is None else row0
@@ -222,9 +223,18 @@ class SvgfDenoiser:
         if not self.pipelined:
             if before_tv is not None:
                 before_tv()
-            frame(d, self.params, row0, row1, stream)
+            # the caller's CURRENT torch stream unless told otherwise (NULL would be unordered with a
+            # `with torch.cuda.stream(s)` block around this call)
+            frame(d, self.params, row0, row1, torch.cuda.current_stream() if stream is None else stream)
         else:
             sa, sb = self.stream_a, self.stream_b
+            # The side streams keep reading color / nd / motion and writing `out` after this call returns (nd
+            # until the NEXT frame's T has run): tell torch's caching allocator, so that a caller who drops or
+            # recycles these tensors does not get their memory handed out again while kernels are in flight.
+            # Results are valid, and inputs may be overwritten, after synchronize().
+            for t in (color, nd, motion, out):
+                t.record_stream(sa)
+                t.record_stream(sb)
             self._params_tv = SvgfParams.from_buffer_copy(self.params)
             if self._params_tv.tv_workgroups == 0:
                 self._params_tv.tv_workgroups = self._tv_workgroups

@@ -138,3 +138,104 @@ def test_frame_threads_do_not_change_result(orc):
     a = orc.Frame(64, 48, *ins); b = orc.Frame(64, 48, *ins)
     orc.frame(a, orc.default_params(), 1); orc.frame(b, orc.default_params(), 4)
     assert (a.out_color == b.out_color).all() and (a.hist_color_out == b.hist_color_out).all()
+
+
+# ---- hand-computed known answers (SURVEY Appendix A evaluated with pencil-and-paper numpy, independent of
+# ---- oracle/svgf_oracle.c: the goldens above only guard the oracle against drift, these pin its meaning) ----
+LUM = np.array([0.2126, 0.7152, 0.0722], np.float64)
+
+
+def test_temporal_blend_weights_by_hand(orc):
+    """T on a 1x1 frame, static camera.  Frame 0 has no history: h = 1, alpha = 1, variance m2 - m1^2 = 0.
+    Frame 1 re-projects onto itself: h = 2, alpha = max(0.05, 1/2), alpha_m = max(0.2, 1/2) (A.T.3-4)."""
+    p = orc.default_params()
+    nd = np.array([[[0.0, 0.0, 1.0, 5.0]]], np.float32)
+    m = np.zeros((1, 1, 2), np.float32)
+    c0 = np.array([[[1.0, 2.0, 4.0, 0.0]]], np.float32)
+    f0 = orc.Frame(1, 1, c0, nd, m)
+    orc.temporal(f0, p)
+    l0 = float(LUM @ c0[0, 0, :3])
+    assert np.allclose(f0.t_color[0, 0], [1, 2, 4, 0], atol=1e-6) and f0.t_debug[0, 0, 3] == 1
+    assert np.allclose(f0.t_moments[0, 0, :3], [l0, l0 * l0, 1], rtol=1e-6)
+    c1 = np.array([[[3.0, 2.0, 0.0, 0.0]]], np.float32)
+    f1 = orc.Frame(1, 1, c1, nd, m, f0.t_color, f0.t_moments, nd)
+    orc.temporal(f1, p)
+    l1 = float(LUM @ c1[0, 0, :3])
+    m1 = 0.5 * l0 + 0.5 * l1
+    m2 = 0.5 * l0 * l0 + 0.5 * l1 * l1
+    assert f1.t_debug[0, 0].tolist() == [0, 0, 1, 2]              # q0 = (0,0); only tap (0,0) is inside the frame; h = 2
+    assert np.allclose(f1.t_color[0, 0, :3], [2.0, 2.0, 2.0], rtol=1e-6)
+    assert abs(f1.t_color[0, 0, 3] - (m2 - m1 * m1)) <= 2e-6 * m2          # fp32 cancellation of two values near 4
+    assert np.allclose(f1.t_moments[0, 0, :3], [m1, m2, 2], rtol=1e-6)
+    # third frame: h = 3, alpha = 1/3, alpha_m = 1/3
+    f2 = orc.Frame(1, 1, c0, nd, m, f1.t_color, f1.t_moments, nd)
+    orc.temporal(f2, p)
+    assert f2.t_debug[0, 0, 3] == 3
+    assert np.allclose(f2.t_color[0, 0, :3], (2.0 * np.array([2, 2, 2]) + np.array([1, 2, 4])) / 3.0, rtol=1e-6)
+
+
+def test_temporal_rejects_history_across_a_depth_or_normal_edge_by_hand(orc):
+    p = orc.default_params()
+    m = np.zeros((1, 1, 2), np.float32)
+    c = np.array([[[1.0, 1.0, 1.0, 0.0]]], np.float32)
+    nd_prev = np.array([[[0.0, 0.0, 1.0, 5.0]]], np.float32)
+    hist_m = np.array([[[1.0, 1.0, 7.0, 0.0]]], np.float32)
+    for nd_cur, ok in (([0, 0, 1, 5.05], True),      # |dz| = 0.05 <= k_z (g_z + 1e-2) = 0.1
+                       ([0, 0, 1, 5.2], False),      # |dz| = 0.2 > 0.1
+                       ([0, 1, 0, 5.0], False)):     # n.n' = 0 < k_n = 0.9
+        f = orc.Frame(1, 1, c, np.array([[nd_cur]], np.float32), m, c, hist_m, nd_prev)
+        orc.temporal(f, p)
+        assert f.t_debug[0, 0, 3] == (8 if ok else 1), nd_cur      # h = min(32, 7 + 1) or a disocclusion
+
+
+def test_atrous_weights_by_hand(orc):
+    """A on a 3x1 frame, iteration 0: the centre pixel sees taps dx = -1, 0, +1 (dy = 0), everything else is out of
+    frame and skipped.  k = 3/8 * {1/4, 3/8, 1/4}; same normal (w_n = 1); z differs on the right tap only."""
+    p = orc.default_params()
+    nd = np.zeros((1, 3, 4), np.float32)
+    nd[..., 2] = 1.0
+    nd[0, :, 3] = [2.0, 2.0, 2.5]
+    col = np.zeros((1, 3, 4), np.float32)
+    col[0, :, :3] = [[1, 1, 1], [1, 1, 1], [3, 3, 3]]
+    col[0, :, 3] = [0.04, 0.04, 0.04]
+    f = orc.Frame(3, 1, col, nd, np.zeros((1, 3, 2), np.float32))
+    out = np.zeros_like(col)
+    orc.atrous(f, p, 0, col, out)
+    # centre pixel x = 1: g_z = |z(2) - z(1)| + |z(1, y+1 clamped) - z(1)| = 0.5; var_c: 3x1 prefilter, weights 1/8 1/4 1/8
+    var_c = 0.04
+    k = np.array([0.25, 0.375, 0.25]) * 0.375
+    lum = np.array([1.0, 1.0, 3.0])
+    w_z = np.array([0.0, 0.0, 0.5 / (1.0 * 0.5 * 1 * 1.0 + 1e-8)])
+    w_l = np.abs(lum[1] - lum) / (4.0 * np.sqrt(var_c) + 1e-8)
+    w = k * np.exp(-w_z - w_l)
+    want_c = (w * lum).sum() / w.sum()
+    want_v = (w * w * 0.04).sum() / w.sum() ** 2
+    assert np.allclose(out[0, 1, :3], want_c, rtol=1e-5)
+    assert np.isclose(out[0, 1, 3], want_v, rtol=1e-5)
+    # a perpendicular normal on the right tap removes it entirely: w_n = max(0, 0)^128 = 0
+    nd2 = nd.copy()
+    nd2[0, 2, :3] = [1.0, 0.0, 0.0]
+    f2 = orc.Frame(3, 1, col, nd2, np.zeros((1, 3, 2), np.float32))
+    orc.atrous(f2, p, 0, col, out)
+    assert np.allclose(out[0, 1, :3], 1.0, rtol=1e-6)
+
+
+def test_atrous_single_pixel_frame_is_the_identity(orc):
+    p = orc.default_params()
+    nd = np.array([[[0.0, 0.6, 0.8, 3.0]]], np.float32)
+    col = np.array([[[0.3, 0.7, 0.1, 0.25]]], np.float32)
+    f = orc.Frame(1, 1, col, nd, np.zeros((1, 1, 2), np.float32))
+    src = col
+    for it in range(5):
+        out = np.zeros_like(col)
+        orc.atrous(f, p, it, src, out)
+        assert np.allclose(out, col, rtol=1e-6), it          # only the centre tap exists: c k / k, var k^2 / k^2
+        src = out
+
+
+def test_demodulation_by_hand(orc):
+    rad = np.array([[[0.5, 0.2, 0.0, 0.7], [1.0, 1.0, 1.0, 0.1]]], np.float32)
+    alb = np.array([[[0.25, 0.8, 0.0, 1.0], [0.5, 0.0005, 2.0, 1.0]]], np.float32)
+    got = orc.demodulate(rad, alb, eps=1e-3)
+    want = np.array([[[2.0, 0.25, 0.0, 0.7], [2.0, 1000.0, 0.5, 0.1]]], np.float32)
+    assert np.allclose(got, want, rtol=1e-6)

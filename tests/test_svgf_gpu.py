@@ -104,7 +104,7 @@ def test_variance_parity(rmd, orc, cuda, width, height):
         assert abs(s[0] - fr.v_color[..., 3].sum()) <= 1e-3 * (1 + fr.v_color[..., 3].sum())
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("width,height", SIZES)
 def test_atrous_each_iteration(rmd, orc, cuda, width, height, variant):
     """Every iteration in isolation (oracle-fed input): direct kernel (1), LDS stream kernel with
@@ -134,14 +134,14 @@ def test_stream_kernel_equals_direct_kernel_bitwise(rmd, cuda, width, height):
     src = c
     for it in range(5):
         outs = []
-        for variant in (1, 2, 3, 5, 4):
+        for variant in (1, 2, 3, 5, 4, 6, 0):
             p.atrous_variant = variant
             o = torch.full_like(c, float("nan"))
             rmd.svgf.atrous(d, p, it, src, o, 0, height)
             outs.append(o)
         torch.cuda.synchronize()
-        for k in (1, 2):
-            assert torch.equal(outs[0], outs[k]), f"iteration {it} variant {k + 1}: {(outs[0] != outs[k]).sum().item()} values differ"
+        for k, name in ((1, 2), (2, 3), (5, 6), (6, 0)):
+            assert torch.equal(outs[0], outs[k]), f"iteration {it} variant {name}: {(outs[0] != outs[k]).sum().item()} values differ"
         assert torch.equal(outs[3], outs[4]), f"iteration {it} pair kernel vs its direct form: {(outs[3] != outs[4]).sum().item()} values differ"
         src = outs[2]
 
@@ -155,7 +155,7 @@ def test_atrous_zero_normals_cornell(rmd, orc, cuda):
     fr = orc.Frame(w, h, color, nd, motion)
     p = orc.default_params()
     d, t, _ = gpu_frame_desc(rmd, fr)
-    for variant in (1, 2, 3, 4, 5):
+    for variant in (0, 1, 2, 3, 4, 5, 6):
         p.atrous_variant = variant
         src = color
         for it in range(5):
@@ -466,6 +466,14 @@ def test_conversions_match_oracle(rmd, orc, cuda):
     al = rng.random((50, 70, 4), dtype=np.float32)
     assert (rmd.svgf.convert_f32_to_u8(dev(f)).cpu().numpy() == orc.convert_f32_to_u8(f)).all()
     assert (rmd.svgf.convert_f32_to_u8(dev(f), dev(al)).cpu().numpy() == orc.convert_f32_to_u8(f, al)).all()
+    # demodulation by albedo (one IEEE division per channel: bit-exact), also in place, black albedo floored at eps
+    al[::7, ::5, :3] = 0.0
+    rad = (rng.random((50, 70, 4), dtype=np.float32) * 4.0)
+    want = orc.demodulate(rad, al, 1e-3)
+    assert (rmd.svgf.demodulate(dev(rad), dev(al), 1e-3).cpu().numpy() == want).all()
+    inplace = dev(rad)
+    rmd.svgf.demodulate(inplace, dev(al), 1e-3, out=inplace)
+    assert (inplace.cpu().numpy() == want).all() and np.isfinite(want).all()
 
 
 def test_4k_properties(rmd, cuda):
@@ -515,7 +523,7 @@ def test_degenerate_frame_sizes(rmd, orc, cuda, width, height):
         torch.cuda.synchronize()
         assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}"
         close(out, fr.out_color, TOL_FRAME, f"{width}x{height} frame {f}")
-    for variant in (1, 2, 3, 4, 5):                         # every a-trous variant on the last frame's input
+    for variant in (0, 1, 2, 3, 4, 5, 6):                   # every a-trous variant on the last frame's input
         p.atrous_variant = variant
         d, t, _ = gpu_frame_desc(rmd, ref[-1])
         src = ref[-1].v_color
