@@ -217,12 +217,27 @@ __device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const 
                                          const Tap& t, float e0A, float e0B, int adx, int adyA, int adyB, float sigma_n)
 {
     const f2 c = tap_cosine<f2>(k, t);
-    const bool tz = ZERO_AWARE && is_zero3(t.n);
-    float ca = c.x, cb = c.y;
-    asm("" : "+v"(ca), "+v"(cb));
-    const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, k.z.x, k.lum.x, k.il.x, xa, t, tz, adx, adyA);
-    const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, k.z.y, k.lum.y, k.il.y, xb, t, tz, adx, adyB);
-    tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t);
+    if constexpr (!ZERO_AWARE) {
+        // Every VALU instruction of this loop costs a full issue slot, so what can be
+        // packed is: sigma_n*log2(cos) + log2 k for both pixels (the two log2 k ride in an SGPR pair; sigma_n
+        // is kept in a VGPR to leave the one scalar operand slot to them) and the two differences; only the
+        // |.|-scaled terms stay scalar (packed f32 has no abs modifier).  Same operations as tap_exponent,
+        // same bits.
+        f2 e = fma_(f2{ sigma_n, sigma_n }, log2_(c), f2{ e0A, e0B });
+        const f2 dz = k.z - f2{ t.n.w, t.n.w }, dl = k.lum - f2{ t.c.x, t.c.x };
+        if (adx | adyA) e.x = fma_(-fabsf(dz.x), xa.iz[len_class(adx, adyA)], e.x);
+        if (adx | adyB) e.y = fma_(-fabsf(dz.y), xb.iz[len_class(adx, adyB)], e.y);
+        e.x = fma_(-fabsf(dl.x), k.il.x, e.x);
+        e.y = fma_(-fabsf(dl.y), k.il.y, e.y);
+        tap_accumulate<f2>(s, exp2_(e), t);
+    } else {
+        const bool tz = is_zero3(t.n);
+        float ca = c.x, cb = c.y;
+        asm("" : "+v"(ca), "+v"(cb));
+        const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, k.z.x, k.lum.x, k.il.x, xa, t, tz, adx, adyA);
+        const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, k.z.y, k.lum.y, k.il.y, xb, t, tz, adx, adyB);
+        tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t);
+    }
 }
 
 // A.A.3.  c = the centre in (lum, r, g, var) form.
@@ -545,6 +560,8 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         }
         // a wave takes the cheaper path when none of its centres has a zero normal
         const bool any_zero = __builtin_amdgcn_ballot_w64(xA.zero || xB.zero) != 0ull;
+        float sn;                                                      // sigma_n in a VGPR (see tap_pair)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));
 
         // The 30 taps of a step are walked in groups of GR window rows (dx outer, rows inner):
         // the ds_read_b128 of group g+1 are issued before group g is weighted, and a scheduling fence
@@ -580,9 +597,9 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
                     // log2 k of the tap, or -inf for a tap outside the frame (w becomes exactly 0)
                     const float e0A = valid ? kLogB3[adx] + kLogB3[adyA] : kNegInf;
                     const float e0B = valid ? kLogB3[adx] + kLogB3[adyB] : kNegInf;
-                    if (tr == 0)      tap_single<ZA>(sA, kA, xA, t[q], e0A, adx, adyA, a.sigma_n);
-                    else if (tr == 5) tap_single<ZA>(sB, kB, xB, t[q], e0B, adx, adyB, a.sigma_n);
-                    else              tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0A, e0B, adx, adyA, adyB, a.sigma_n);
+                    if (tr == 0)      tap_single<ZA>(sA, kA, xA, t[q], e0A, adx, adyA, sn);
+                    else if (tr == 5) tap_single<ZA>(sB, kB, xB, t[q], e0B, adx, adyB, sn);
+                    else              tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0A, e0B, adx, adyA, adyB, sn);
                 }
             };
             Tap t0[GR], t1[GR];

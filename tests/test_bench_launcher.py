@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -14,7 +16,7 @@ def run_bench(*argv, **env):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)                      # the shape of the driver's N = 1 command: no launcher environment
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, capture_output=True,
-                          text=True, timeout=300)
+                          text=True, timeout=600)
 
 
 def test_parent_starts_the_ranks_and_relays_rank0():
@@ -40,3 +42,23 @@ def test_launcher_does_not_import_torch_or_the_library_in_the_parent():
         assert not line.startswith(("import torch", "from torch", "import raymarchdenoisercuda_amd")), line
     body = src[src.index("def main()"):]
     assert body.index("launch_ranks(args)") < body.index("import torch")
+
+
+
+@pytest.mark.gpu
+def test_two_rank_strong_scaling_bench_runs_without_a_launcher():
+    """`python bench.py --gpus 2` exactly as the driver calls N = 1 (no launcher, no WORLD_SIZE): the parent starts
+    both ranks, they cut the fixed 8K frame of BASELINE configs[3] into two strips and exchange the history
+    halo every frame.  On the one-GPU box the two ranks share the device, so the exchange runs over gloo
+    (RCCL refuses two ranks on one GPU); with one GPU per rank the same code path uses backend "nccl"."""
+    r = run_bench("--gpus", "2", "--steps", "3", "--warmup", "2", "--no-other-sizes", "--roofline-reps", "3",
+                  RMD_DIST_BACKEND="gloo")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["config"]["frame"] == [7680, 4320] and d["config"]["rows_per_gpu"] == 2160
+    assert "configs[3]" in d["config"]["workload"]
+    assert d["halo_bytes_per_frame_rank0"] == (13 + 8) * 7680 * 16          # rows 60..73 of hist_color, 65..73 of hist_moments
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0
