@@ -136,8 +136,7 @@ typedef struct rmd_svgf_params {
     float sigma_l;          /* 4   */
     int   iterations;       /* 5   step 2^i for i in [0, iterations)                           */
     int   hist_iteration;   /* 0   output of this iteration becomes next frame's hist_color    */
-    int   atrous_variant;   /* 0 auto (3 or 6 for iterations 0..4, whichever decomposes the frame better; 1
-                                   beyond) | row-pair formulation: 1 direct (taps from global memory, any step),
+    int   atrous_variant;   /* 0 auto (= 3 for iterations 0..4, 1 beyond) | row-pair formulation: 1 direct (taps from global memory, any step),
                                    2 / 3 / 6 LDS row streaming with one / two / four row pairs per workgroup |
                                    pixel-pair formulation: 4 LDS row streaming, 5 direct.  0, 1, 2, 3, 6 give
                                    identical bits, so do 4 and 5 (the two families differ in the order of

@@ -1469,20 +1469,18 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
     return launch_planned<S, NP>(a, stream);
 }
 
-// Library default: 128-column strips with two row pairs per step (NP = 2), unless 64-column strips with four
-// (NP = 4, bands of 8S rows, (64 + 4S) staged columns per 64) decompose the frame clearly better.  At equal
-// decomposition efficiency the two run at the same speed (bench.py, 4K: 125 / 131 / 132 / 133 / 140 us against
-// 127 / 132 / 131 / 139 / 142 us per iteration); at step 16 the staged strips would be twice their width: never.
+// Library default: 128-column strips with two row pairs per step (NP = 2).  The other two decompositions were
+// measured against it with bench.py's timing and never won: four row pairs on 64-column strips (NP = 4: 127 /
+// 132 / 131 / 139 / 142 us per 4K iteration against 125 / 131 / 132 / 133 / 140) and one row pair on 256-column
+// strips (NP = 1, two workgroups per CU: 84 us per iteration on a 7680x540 strip against 74-80, and 84.5 against
+// 86.4 only at step 16, where NP = 2 has 960 workgroups for 768 slots).  RMD_ATROUS_NP = 1 | 4 forces them.
 template <int S>
 static int launch_stream_auto(AtrousArgs a, hipStream_t stream)
 {
-    constexpr double kGain4 = S <= 8 ? 0.95 : 0.0;
     static const int force = [] { const char* e = getenv("RMD_ATROUS_NP"); return e ? atoi(e) : 0; }();
-    AtrousArgs a2 = a, a4 = a;
-    const double e2 = plan_stream<S, 2>(a2);
-    const double e4 = kGain4 > 0.0 ? plan_stream<S, 4>(a4) * kGain4 : 0.0;
-    const bool four = force == 4 ? kGain4 > 0.0 : (force == 2 ? false : e4 > e2);
-    return four ? launch_planned<S, 4>(a4, stream) : launch_planned<S, 2>(a2, stream);
+    if (force == 1) return launch_stream<S, 1>(a, stream);
+    if (force == 4 && S <= 8) return launch_stream<S, 4>(a, stream);
+    return launch_stream<S, 2>(a, stream);
 }
 
 template <int NP>
