@@ -493,6 +493,43 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         }
     };
 
+    // The same fetches as load_rows + load_aux, ONE vector-memory instruction per call, for the interior form:
+    // issued one per tap group inside the tap loop instead of together at the top of a step, where 4 waves x ~13
+    // of them queue up in the CU's texture address unit and every wave stalls at issue (tools/atrous_trace.py:
+    // 16-23 % of a step).  Unconditional, at clamped rows (the last step fetches rows nobody uses; rows of
+    // dropped outputs read something harmless), so no branch joins inside the loop.
+    constexpr int kPieces = 4 + C::NT + 7;
+    const int blo_i = max(g.buf_row0, 0), bhi_i = min(g.buf_row0 + g.buf_rows, g.H);
+    auto clamp_row = [&](const int y) { return min(max(y, blo_i), bhi_i - 1); };
+    auto prefetch_piece = [&](const int i, const int jb, const int jo) {
+        if (i < 4) {
+            const int r = i >> 1;
+            const long long o = row_base(clamp_row(ybase + (jb + 2 * pr + r) * S), x0 - 2 * S);
+            if (i & 1) pn[r] = (a.nd + o)[col]; else pc[r] = (a.in + o)[col];
+        } else if (i < 4 + C::NT) {
+            const int q = i - 4;
+            const int e = min(tid + q * 256, C::TAIL - 1);
+            const int sel = e / (4 * S);
+            const int y = clamp_row(ybase + (jb + (sel >> 1)) * S);
+            const int gx = x0 - 2 * S + C::CW + e % (4 * S);
+            const float4* plane = (sel & 1) ? a.nd : a.in;
+            pe[q] = plane[(size_t)(y - g.buf_row0) * (size_t)g.W + (size_t)gx];
+        } else if (i < 4 + C::NT + 6) {
+            const int k = i - 4 - C::NT, r = k / 3, which = k % 3;
+            const int y = clamp_row(ybase + (jo + 2 * pr + r) * S);
+            if (which == 0)      pvu[r] = (in_f + row_base(clamp_row(y - 1), x0) * 4 + 3)[col * 4];
+            else if (which == 1) pvd[r] = (in_f + row_base(clamp_row(y + 1), x0) * 4 + 3)[col * 4];
+            else                 pzd[r] = (nd_f + row_base(clamp_row(y + 1), x0) * 4 + 3)[col * 4];
+        } else {
+            // halo columns x0-1 and x0+CW of the 4*NP variance rows: lanes 0 .. 8NP-1 keep theirs
+            const int t8 = tid & (8 * NP - 1);
+            const int ii = t8 >> 2, ud = (t8 >> 1) & 1, side = t8 & 1;
+            const int yy = clamp_row(ybase + (jo + ii) * S + (ud ? 1 : -1));
+            const int xx = side ? x0 + C::CW : x0 - 1;
+            pvh = in_f[((size_t)(yy - g.buf_row0) * (size_t)g.W + (size_t)xx) * 4 + 3];
+        }
+    };
+
     // ---- per-pixel setup (A.A.1 prefilter, depth gradient) from the staged data
     auto setup = [&](const int i, const int y, const int rb_center, const Tap& t, Center<float>& k, CenterAux& aux) {
         const int ccol = rb_center + 2 * S * 16;      // byte offset of the centre pixel in the color plane
@@ -604,8 +641,10 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             };
             Tap t0[GR], t1[GR];
             load_grp(0, t0);
+            static_assert(kPieces <= NG || EDGE, "one refill instruction per tap group");
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
+                if (!EDGE && grp < kPieces) prefetch_piece(grp, j - 2 + C::NR, j + C::ADV);
                 if (grp & 1) { if (grp < NG - 1) load_grp(grp + 1, t0); weigh_grp(grp, t1); }
                 else         { if (grp < NG - 1) load_grp(grp + 1, t1); weigh_grp(grp, t0); }
                 __builtin_amdgcn_sched_barrier(0);
@@ -663,7 +702,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         else if (j >= jq2) __builtin_amdgcn_s_setprio(1);
         else if (j >= jq1) __builtin_amdgcn_s_setprio(2);
         const bool more = j + C::ADV < jhi;
-        if (more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute
+        if (EDGE && more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute (interior form: inside compute)
         RMD_PHASE(0)
         compute(j);
         RMD_PHASE(1)
