@@ -664,8 +664,14 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         const int jw = j + 2 * pr;
         const int yA = ybase + jw * S;
         if (xin) {
-            if (jw >= jlo && jw < jhi) (a.out + row_base(yA, x0))[col] = outA;
-            if (jw + 1 >= jlo && jw + 1 < jhi) (a.out + row_base(yA + S, x0))[col] = outB;
+            // Non-temporal stores: the 133 MB a 4K launch writes are the expensive third of its traffic (the
+            // skeleton without them runs at 5.4 TB/s, with them at 4.85), and nothing reads an output row
+            // again before the next launch.  Launch for launch 131-145 -> 121-131 us, inside a frame 0.960 ->
+            // 0.948 ms (the next iteration then fetches all of its input from HBM).  Non-temporal LOADS of the
+            // colour plane lose: its halo columns are shared with the neighbour strip through L2.
+            typedef float f4n __attribute__((ext_vector_type(4)));
+            if (jw >= jlo && jw < jhi) __builtin_nontemporal_store(f4n{ outA.x, outA.y, outA.z, outA.w }, reinterpret_cast<f4n*>(a.out + row_base(yA, x0)) + col);
+            if (jw + 1 >= jlo && jw + 1 < jhi) __builtin_nontemporal_store(f4n{ outB.x, outB.y, outB.z, outB.w }, reinterpret_cast<f4n*>(a.out + row_base(yA + S, x0)) + col);
         }
     };
 
