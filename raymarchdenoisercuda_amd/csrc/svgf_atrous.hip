@@ -64,6 +64,7 @@ struct AtrousArgs {
     // pair kernel: strips that touch the left / right frame border run the slower per-lane-tested body and get
     // bands of half the height (xe_lo of them at the left, the rest of the non-interior ones at the right)
     int n_int, xe_lo, band_h_xe, total_int, int_per_xcd, xe_per_xcd;
+    int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
 };
 
 // log2 of the B3-spline taps {3/8, 1/4, 1/16} (reference src/filter.cu:10)
@@ -669,9 +670,16 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             // again before the next launch.  Launch for launch 131-145 -> 121-131 us, inside a frame 0.960 ->
             // 0.948 ms (the next iteration then fetches all of its input from HBM).  Non-temporal LOADS of the
             // colour plane lose: its halo columns are shared with the neighbour strip through L2.
+            // Only where the launch's three planes overflow the Infinity Cache anyway: a smaller launch (one rank's
+            // strip of an 8K frame: 3 x 84 MB) finds its input still cached if the previous one stored normally.
             typedef float f4n __attribute__((ext_vector_type(4)));
-            if (jw >= jlo && jw < jhi) __builtin_nontemporal_store(f4n{ outA.x, outA.y, outA.z, outA.w }, reinterpret_cast<f4n*>(a.out + row_base(yA, x0)) + col);
-            if (jw + 1 >= jlo && jw + 1 < jhi) __builtin_nontemporal_store(f4n{ outB.x, outB.y, outB.z, outB.w }, reinterpret_cast<f4n*>(a.out + row_base(yA + S, x0)) + col);
+            if (a.nt_out) {
+                if (jw >= jlo && jw < jhi) __builtin_nontemporal_store(f4n{ outA.x, outA.y, outA.z, outA.w }, reinterpret_cast<f4n*>(a.out + row_base(yA, x0)) + col);
+                if (jw + 1 >= jlo && jw + 1 < jhi) __builtin_nontemporal_store(f4n{ outB.x, outB.y, outB.z, outB.w }, reinterpret_cast<f4n*>(a.out + row_base(yA + S, x0)) + col);
+            } else {
+                if (jw >= jlo && jw < jhi) (a.out + row_base(yA, x0))[col] = outA;
+                if (jw + 1 >= jlo && jw + 1 < jhi) (a.out + row_base(yA + S, x0))[col] = outB;
+            }
         }
     };
 
@@ -1578,6 +1586,7 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z; a.sigma_l = p->sigma_l;
     a.band_h = a.band_base = a.nstrips = a.nblocks = a.per_xcd = 0;
     a.n_int = a.xe_lo = a.band_h_xe = a.total_int = a.int_per_xcd = a.xe_per_xcd = 0;
+    a.nt_out = (double)(row1 - row0) * f->width * 48.0 > 256.0e6 ? 1 : 0;
 
     int variant = p->atrous_variant;
     if (variant == 0) {
