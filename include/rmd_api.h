@@ -138,9 +138,10 @@ typedef struct rmd_svgf_params {
     int   hist_iteration;   /* 0   output of this iteration becomes next frame's hist_color    */
     int   atrous_variant;   /* 0 auto (= 3 for iterations 0..4, 1 beyond) | row-pair formulation: 1 direct (taps from global memory, any step),
                                    2 / 3 / 6 LDS row streaming with one / two / four row pairs per workgroup |
-                                   pixel-pair formulation: 4 LDS row streaming, 5 direct.  0, 1, 2, 3, 6 give
-                                   identical bits, so do 4 and 5 (the two families differ in the order of
-                                   summation, i.e. by rounding)                                           */
+                                   pixel-pair formulation: 4 LDS row streaming, 5 direct, 7 LDS row streaming with
+                                   loader waves feeding compute waves through counters instead of barriers
+                                   (experiment, slower: DESIGN.md §4.6).  0, 1, 2, 3, 6 give identical bits, so do
+                                   4, 5 and 7 (the two families differ in the order of summation, i.e. by rounding) */
     int   tv_workgroups;    /* 0   T and V as one workgroup per 64x4 tile (default, fastest) | N > 0: N persistent
                                    workgroups that walk the tiles: a constant register footprint beside another
                                    frame's a-trous launches (experimental, slower so far); same results either way */
@@ -190,6 +191,9 @@ int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, in
  * buffer geometry as f; f->nd supplies normals/depth). */
 int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
                     const float* in, float* out, int row0, int row1, void* stream);
+/* Variant 7 synchronises its waves with counters in LDS; every wait is bounded, and a wait that runs out
+ * is counted here instead of hanging the GPU (synchronises the device; 0 after any number of correct launches). */
+int rmd_debug_atrous_protocol_errors(unsigned int* count);
 /* T + V + `iterations` x A for final output rows [row0,row1).  Earlier passes are computed on
  * the rows later passes tap (redundant rows instead of per-pass halo exchanges);
  * those rows are clamped to the global frame and must lie inside the buffer. */

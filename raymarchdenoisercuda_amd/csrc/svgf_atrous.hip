@@ -1395,13 +1395,460 @@ __global__ __launch_bounds__(256, 3) void atrous_pair_kernel(AtrousArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------- loader / consumer form
+// The pixel-pair arithmetic with staging taken out of the compute waves (variant 7).  The ablations of the two
+// kernels above say a step is a chain -- refill loads, 25 x [LDS reads, arithmetic], barrier, LDS stores,
+// barrier -- that overlaps only through the other workgroups of the CU, with the refill one step deep.  Here a
+// workgroup is 4 compute waves + 1 LOADER wave:
+//   loader    streams "packages" k = 0, 1, 2 ... (lattice row j0-2+k of the strip + the variance rows above and
+//             below output row k-4) through a register pipeline three packages deep into the LDS ring, and
+//             publishes a monotonic count of finished packages;
+//   consumers wait for the count to cover the five rows of their output row, compute it (same code path as the
+//             barrier form), store it, and publish how many steps they have finished -- which is what the loader
+//             reads before it overwrites a ring slot.  No workgroup barrier after the prologue.
+// Every spin is bounded: a protocol bug ends in wrong pixels and an error flag, never in a hang.
+#ifndef RMD_LC_DEPTH
+#define RMD_LC_DEPTH 3
+#endif
 template <int S>
+struct LcCfg {
+    using P = PairCfg<S>;
+    // Wave placement decides the shape.  With 128 VGPRs a SIMD holds 4 waves and a workgroup's waves are dealt
+    // round-robin over the SIMDs:
+    //   4 + 1 waves  three workgroups per CU by LDS, but only two became resident (a SIMD would have needed 6 waves)
+    //   6 + 2 waves  two workgroups fill the CU; consumers sit 4 / 4 / 2 / 2 on the SIMDs          <- default
+    //   12 + 4 waves one workgroup per CU, 3 consumers + 1 loader on every SIMD (-DRMD_LC_NC=12 -DRMD_LC_NL=4)
+    // Measured at 4K, steps 2..16: 6+2 150 us, 12+4 170 us per launch -- and 130 us for the 12+4
+    // consumers ALONE (loaders idle, no waits): the arithmetic, not the staging, is what the launch time is made of.
+#ifndef RMD_LC_NC
+#define RMD_LC_NC 6
+#define RMD_LC_NL 2
+#endif
+    static constexpr int NC = RMD_LC_NC, NL = RMD_LC_NL;   // consumer waves (one output row each per step), loader waves
+    static constexpr int THREADS = 64 * (NC + NL);
+    static constexpr int WG_PER_CU = 16 / (NC + NL);
+    static constexpr int NR = NC == 12 ? 22 : 12;           // ring rows: the NC + 4 of a step + spare
+    static constexpr int RING_BYTES = NR * P::ROW_BYTES;
+    static constexpr int AUX_OFF = RING_BYTES;       // var(y-1), var(y+1) per consumer wave (a slot belongs to its wave alone)
+    static constexpr int FLAG_OFF = AUX_OFF + NC * 2 * P::AUX_ROW;
+    static constexpr int LDS_BYTES = FLAG_OFF + 128; // [0..NL) packages committed by loader l, [4..4+NC) steps done by consumer w, [16] error
+    static_assert(NL <= 4 && NC <= 12, "flag layout");
+    static_assert(WG_PER_CU * LDS_BYTES <= 160 * 1024, "LDS of a CU");
+};
+__device__ unsigned int g_atrous_lc_errors;          // protocol time-outs (0 in a correct build): rmd_debug_atrous_protocol_errors
+
+typedef volatile __attribute__((address_space(3))) int lds_flag;
+
+template <int S, bool XE>
+__device__ __forceinline__ void atrous_lc_body(const AtrousArgs& a, unsigned char* lds, const int tid,
+                                               const int x0, const int ybase, const int jlo, const int jhi)
+{
+    using C = PairCfg<S>;
+    using L = LcCfg<S>;
+    const Geom g = a.g;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..NC-1 consumers, then the loaders
+    const int blo = max(g.buf_row0, 0), bhi = min(g.buf_row0 + g.buf_rows, g.H);
+    const int j0 = jlo;
+    const int nsteps = (jhi - j0 + L::NC - 1) / L::NC;
+    const int nrows = L::NC * nsteps;
+    const int npk = nrows + 4;                                     // packages: lattice rows j0-2 .. j0+nrows+1
+    lds_flag* flags = (lds_flag*)(lds + L::FLAG_OFF);
+    constexpr int kSpinLimit = 1 << 22;
+    if (tid < 32) flags[tid] = 0;
+    __syncthreads();
+
+    if (wv >= L::NC) {
+        // =============================================================== loaders: packages k = ld, ld + NL, ...
+        const int ld = wv - L::NC;
+#ifndef RMD_LC_PRIO0
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        const float* in_f = reinterpret_cast<const float*>(a.in);
+        int gofs[3], sofs[3];
+        float keepx[3];
+        bool sact[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int col = lane + 64 * q;
+            sact[q] = col < C::PW;
+            const int colc = min(col, C::PW - 1);
+            const int gx = x0 - 2 * S + colc;
+            keepx[q] = (!XE || (gx >= 0 && gx < g.W)) ? 1.0f : 0.0f;
+            gofs[q] = XE ? min(max(gx, 0), g.W - 1) : gx;
+            sofs[q] = (colc >> 1) * 16 + (colc & 1) * 4;
+        }
+        struct Pkg { float4 c[3], n[3]; };
+        auto issue = [&](const int k, Pkg& p) {                    // 6 vector-memory instructions, unconditional
+            const int y = ybase + (j0 - 2 + k) * S;
+            const int yc = min(max(y, blo), bhi - 1);
+            const float4* rc = a.in + (size_t)(yc - g.buf_row0) * (size_t)g.W;
+            const float4* rn = a.nd + (size_t)(yc - g.buf_row0) * (size_t)g.W;
+#pragma unroll
+#ifdef RMD_LC_ABL_NOLOAD
+            for (int q = 0; q < 3; ++q) { p.c[q] = float4{ (float)k, 1.0f, 2.0f, 0.1f }; p.n[q] = float4{ 0.0f, 0.0f, 1.0f, (float)gofs[q] }; }
+#else
+            for (int q = 0; q < 3; ++q) { p.c[q] = rc[gofs[q]]; p.n[q] = rn[gofs[q]]; }
+#endif
+        };
+        int seen[L::NC] = {};                                      // steps finished by consumer wave w, as last read
+#ifdef RMD_ATROUS_TRACE
+        unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
+#endif
+        auto commit = [&](const int k, const Pkg& p) {
+            RMD_PHASE(7)
+            // The ring slot held package k-NR, whose last reader is output row k-NR.  Output row q is step q/NC of
+            // wave q%NC and a wave finishes its rows in order: wave w must have finished its last row <= k-NR.
+            const int m = k - L::NR;
+            if (m >= 0) {
+                int need[L::NC];
+#pragma unroll
+                for (int w = 0; w < L::NC; ++w) {
+                    const int qw = m - (m - w + L::NC) % L::NC;
+                    need[w] = qw >= 0 ? qw / L::NC + 1 : 0;
+                }
+                auto behind = [&]() {
+                    bool b = false;
+#pragma unroll
+                    for (int w = 0; w < L::NC; ++w) b = b || seen[w] < need[w];
+                    return b;
+                };
+                int spins = 0;
+#ifdef RMD_LC_ABL_NOSYNC
+                if (false)
+#endif
+                while (behind()) {
+#pragma unroll
+                    for (int w = 0; w < L::NC; ++w) seen[w] = __builtin_amdgcn_readfirstlane(flags[4 + w]);
+                    if (!behind()) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > kSpinLimit) { if (lane == 0) { flags[16] = 1; atomicAdd(&g_atrous_lc_errors, 1u); } break; }
+                }
+            }
+            RMD_PHASE(5)
+            const int y = ybase + (j0 - 2 + k) * S;
+            const float krow = (y >= blo && y < bhi) ? 1.0f : 0.0f;
+            unsigned char* row = lds + (k % L::NR) * C::ROW_BYTES;
+            constexpr int PF = C::PLANE / 4;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (sact[q]) {
+                    float* w = reinterpret_cast<float*>(row + sofs[q]);
+                    const float kk = XE ? krow * keepx[q] : krow;
+                    w[0 * PF] = lum3(p.c[q].x, p.c[q].y, p.c[q].z); w[0 * PF + 2] = p.c[q].x;
+                    w[1 * PF] = p.c[q].y;                            w[1 * PF + 2] = p.c[q].w;
+                    w[2 * PF] = p.n[q].x * kk;                       w[2 * PF + 2] = p.n[q].y * kk;
+                    w[3 * PF] = p.n[q].z * kk;                       w[3 * PF + 2] = p.n[q].w;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the rows are in LDS before the count says so
+            if (lane == 0) flags[ld] = k / L::NL + 1;              // packages this loader has committed
+            RMD_PHASE(6)
+        };
+        constexpr int D = RMD_LC_DEPTH;                            // packages in flight per loader (its registers are the buffer)
+        Pkg p[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) issue(min(ld + L::NL * i, npk - 1), p[i]);
+        for (int k = ld; k < npk; k += L::NL * D) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int ki = k + L::NL * i;
+                if (ki < npk) commit(ki, p[i]);
+                issue(min(ki + L::NL * D, npk - 1), p[i]);
+            }
+        }
+#ifdef RMD_ATROUS_TRACE
+        if (lane == 0 && blockIdx.x < 8192 && ld == 0)
+            for (int i = 5; i < 8; ++i) g_atrous_phase[8 * blockIdx.x + i] = ph[i];
+#endif
+        return;
+    }
+
+    // ================================================================= consumers
+    const int xA = x0 + 2 * lane;
+    const bool inA = !XE || xA < g.W, inB = !XE || xA + 1 < g.W;
+    const float* nd_f = reinterpret_cast<const float*>(a.nd);
+    int zofs[2];
+    zofs[0] = (XE ? min(xA, g.W - 1) : xA) * 4 + 3;
+    zofs[1] = (XE ? min(xA + 1, g.W - 1) : xA + 1) * 4 + 3;
+    auto load_zd = [&](const int q) {                              // z of row y+1 at the lane's own pixels, output row q
+        const int y = min(max(ybase + (j0 + q) * S, blo), bhi - 1);
+        const float* zr = nd_f + (size_t)(min(y + 1, bhi - 1) - g.buf_row0) * (size_t)g.W * 4;
+        return f2{ zr[zofs[0]], zr[zofs[1]] };
+    };
+    f2 zd_next = load_zd(wv);
+    // variance rows above and below the wave's own output row: slot `wv` of the aux ring belongs to this wave alone
+    const float* in_f = reinterpret_cast<const float*>(a.in);
+    int aofs[3];
+    {
+        const int g0 = x0 - 2 + lane, g1 = g0 + 64, g2 = x0 + C::CW - 2 + (lane & 3);
+        aofs[0] = (XE ? min(max(g0, 0), g.W - 1) : g0) * 4 + 3;
+        aofs[1] = (XE ? min(max(g1, 0), g.W - 1) : g1) * 4 + 3;
+        aofs[2] = (XE ? min(max(g2, 0), g.W - 1) : g2) * 4 + 3;
+    }
+    float au[6];
+    auto load_aux = [&](const int q) {
+        const int yo = min(max(ybase + (j0 + q) * S, blo), bhi - 1);
+        const float* up = in_f + (size_t)(max(yo - 1, blo) - g.buf_row0) * (size_t)g.W * 4;
+        const float* dn = in_f + (size_t)(min(yo + 1, bhi - 1) - g.buf_row0) * (size_t)g.W * 4;
+        au[0] = up[aofs[0]]; au[1] = up[aofs[1]]; au[2] = up[aofs[2]];
+        au[3] = dn[aofs[0]]; au[4] = dn[aofs[1]]; au[5] = dn[aofs[2]];
+    };
+    auto store_aux = [&]() {
+        float* ax = reinterpret_cast<float*>(lds + L::AUX_OFF + wv * 2 * C::AUX_ROW);
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            ax[r * C::AUXW + lane] = au[3 * r + 0];
+            ax[r * C::AUXW + 64 + lane] = au[3 * r + 1];
+            if (lane < 4) ax[r * C::AUXW + C::CW + lane] = au[3 * r + 2];
+        }
+    };
+    load_aux(wv);
+    store_aux();
+    int seen_ready[L::NL] = {};
+#ifdef RMD_ATROUS_TRACE
+    unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
+#endif
+    for (int t = 0; t < nsteps; ++t) {
+        const int q = L::NC * t + wv;                              // output row (package numbering: lattice row j0 + q)
+        const int jw = j0 + q;
+        const int y = ybase + jw * S;
+        const f2 zd = zd_next;
+#ifndef RMD_LC_ABL_NOOUT
+        zd_next = load_zd(min(q + L::NC, nrows - 1));
+        load_aux(min(q + L::NC, nrows - 1));
+#endif
+        RMD_PHASE(2)
+        {
+            // main rows q .. q+4 = packages 0 .. q+4: (q + 4 - l) / NL + 1 of them come from loader l
+            int need[L::NL];
+#pragma unroll
+            for (int l = 0; l < L::NL; ++l) need[l] = (q + 4 - l + L::NL) / L::NL;
+            auto behind = [&]() {
+                bool b = false;
+#pragma unroll
+                for (int l = 0; l < L::NL; ++l) b = b || seen_ready[l] < need[l];
+                return b;
+            };
+            int spins = 0;
+#ifdef RMD_LC_ABL_NOSYNC
+            if (false)
+#endif
+            while (behind()) {
+#pragma unroll
+                for (int l = 0; l < L::NL; ++l) seen_ready[l] = __builtin_amdgcn_readfirstlane(flags[l]);
+                if (!behind()) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > kSpinLimit) { if (lane == 0) { flags[16] = 1; atomicAdd(&g_atrous_lc_errors, 1u); } break; }
+            }
+        }
+        RMD_PHASE(0)
+        int rb[5];
+#pragma unroll
+        for (int tr = 0; tr < 5; ++tr) rb[tr] = ((q + tr) % L::NR) * C::ROW_BYTES + (S + lane) * 16;
+        const int cb = rb[2];
+        CenterT<f2> k;
+        const f2 cv = lds_f2(lds, cb + 1 * C::PLANE + 8);
+        { const TwoPairs u = lds_quad_at(lds, cb + 2 * C::PLANE); k.nx = u.a; k.ny = u.b; }
+        { const TwoPairs u = lds_quad_at(lds, cb + 3 * C::PLANE); k.nz = u.a; k.z = u.b; }
+        k.l = lds_f2(lds, cb + 0 * C::PLANE);
+        const bool zA = k.nx.x == 0.0f && k.ny.x == 0.0f && k.nz.x == 0.0f, zB = k.nx.y == 0.0f && k.ny.y == 0.0f && k.nz.y == 0.0f;
+        k.zc = f2{ zA ? 1.0f : 0.0f, zB ? 1.0f : 0.0f };
+        const unsigned char* axb = lds + L::AUX_OFF + wv * 2 * C::AUX_ROW + lane * 8;
+        const f2 vu_l = lds_f2u(axb, 0 * C::AUX_ROW + 4), vu_c = lds_f2(axb, 0 * C::AUX_ROW + 8), vu_r = lds_f2u(axb, 0 * C::AUX_ROW + 12);
+        const f2 vd_l = lds_f2u(axb, 1 * C::AUX_ROW + 4), vd_c = lds_f2(axb, 1 * C::AUX_ROW + 8), vd_r = lds_f2u(axb, 1 * C::AUX_ROW + 12);
+        const f2 vm_l = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 - 12), vm_r = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 + 4);
+        f2 zr = lds_odd_pair(lds, cb + 3 * C::PLANE + 8 + 4);
+        const bool oku = y - 1 >= 0, okd = y + 1 < g.H;
+        // (the six aux reads above have returned before their values are used below; the slot is rewritten at the
+        //  end of the step, in program order of this wave)
+        f2 var_c;
+        if (!XE && oku && okd) {
+            f2 v = splat(0.0625f, f2{}) * vu_l;
+            v = fma_(splat(0.125f, f2{}), vm_l, v);  v = fma_(splat(0.0625f, f2{}), vd_l, v);
+            v = fma_(splat(0.125f, f2{}), vu_c, v);  v = fma_(splat(0.25f, f2{}), cv, v);   v = fma_(splat(0.125f, f2{}), vd_c, v);
+            v = fma_(splat(0.0625f, f2{}), vu_r, v); v = fma_(splat(0.125f, f2{}), vm_r, v); v = fma_(splat(0.0625f, f2{}), vd_r, v);
+            var_c = v;
+        } else {
+            float vcs[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int x = xA + i;
+                const bool okl = !XE || x - 1 >= 0, okr = !XE || x + 1 < g.W;
+                const float ul = i ? vu_l.y : vu_l.x, uc = i ? vu_c.y : vu_c.x, ur = i ? vu_r.y : vu_r.x;
+                const float dl = i ? vd_l.y : vd_l.x, dc = i ? vd_c.y : vd_c.x, dr = i ? vd_r.y : vd_r.x;
+                const float ml = i ? vm_l.y : vm_l.x, mr = i ? vm_r.y : vm_r.x, mc = i ? cv.y : cv.x;
+                if (okl && okr && oku && okd) { vcs[i] = prefilter9(ul, ml, dl, uc, mc, dc, ur, mr, dr); continue; }
+                float gs = 0.25f, vs = 0.25f * mc;
+                if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, ul, vs); }
+                if (okl)        { gs += 0.125f;  vs = fma_(0.125f, ml, vs); }
+                if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, dl, vs); }
+                if (oku)        { gs += 0.125f;  vs = fma_(0.125f, uc, vs); }
+                if (okd)        { gs += 0.125f;  vs = fma_(0.125f, dc, vs); }
+                if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, ur, vs); }
+                if (okr)        { gs += 0.125f;  vs = fma_(0.125f, mr, vs); }
+                if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, dr, vs); }
+                vcs[i] = vs / gs;
+            }
+            var_c = f2{ vcs[0], vcs[1] };
+        }
+        if (XE) {
+            if (xA + 1 >= g.W) zr.x = k.z.x;
+            if (xA + 2 >= g.W) zr.y = k.z.y;
+        }
+        const f2 gz = f2{ fabsf(zr.x - k.z.x) + fabsf(zd.x - k.z.x), fabsf(zr.y - k.z.y) + fabsf(zd.y - k.z.y) };
+        center_consts<f2>(k, var_c, gz, a.sigma_z, a.sigma_l, (float)S);
+        bool rowv[5];
+#pragma unroll
+        for (int tr = 0; tr < 5; ++tr) {
+            const int yy = y + (tr - 2) * S;
+            rowv[tr] = yy >= 0 && yy < g.H;
+        }
+        const bool any_zero = __builtin_amdgcn_ballot_w64((zA && inA) || (zB && inB)) != 0ull;
+        float sn = a.sigma_n;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));
+        const f2 sn2 = splat(sn, f2{});
+        AccT<f2> acc = { f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
+        auto load_tap = [&](const int ti, TapT<f2>& tp) {
+#ifdef RMD_LC_ABL_NOLDS
+            // ablation: no LDS reads -- the tap values are register values the compiler cannot see through
+            tp.l = k.l; tp.r = k.nx; tp.g = k.ny; tp.v = k.nz; tp.nx = k.nx; tp.ny = k.ny; tp.nz = k.nz; tp.z = k.z;
+            asm volatile("" : "+v"(tp.l), "+v"(tp.r), "+v"(tp.g), "+v"(tp.v), "+v"(tp.nx), "+v"(tp.ny), "+v"(tp.nz), "+v"(tp.z));
+            return;
+#endif
+            const int dxi = ti / 5, tr = ti % 5;
+            const int sdx = (dxi - 2) * S;
+            if ((sdx & 1) == 0) {
+                const int off = rb[tr] + (sdx / 2) * 16;
+                { const TwoPairs u = lds_quad_at(lds, off + 0 * C::PLANE); tp.l = u.a; tp.r = u.b; }
+                { const TwoPairs u = lds_quad_at(lds, off + 1 * C::PLANE); tp.g = u.a; tp.v = u.b; }
+                { const TwoPairs u = lds_quad_at(lds, off + 2 * C::PLANE); tp.nx = u.a; tp.ny = u.b; }
+                { const TwoPairs u = lds_quad_at(lds, off + 3 * C::PLANE); tp.nz = u.a; tp.z = u.b; }
+            } else {
+                const int off = rb[tr] + ((sdx - 1) / 2) * 16 + 4;
+                tp.l = lds_odd_pair(lds, off + 0 * C::PLANE);  tp.r = lds_odd_pair(lds, off + 0 * C::PLANE + 8);
+                tp.g = lds_odd_pair(lds, off + 1 * C::PLANE);  tp.v = lds_odd_pair(lds, off + 1 * C::PLANE + 8);
+                tp.nx = lds_odd_pair(lds, off + 2 * C::PLANE); tp.ny = lds_odd_pair(lds, off + 2 * C::PLANE + 8);
+                tp.nz = lds_odd_pair(lds, off + 3 * C::PLANE); tp.z = lds_odd_pair(lds, off + 3 * C::PLANE + 8);
+            }
+        };
+        auto taps = [&](auto zero_aware) {
+            constexpr bool ZA = decltype(zero_aware)::value;
+            auto weigh = [&](const int ti, const TapT<f2>& tp) {
+                const int dx = ti / 5 - 2, dy = ti % 5 - 2;
+                const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+                if (dx == 0 && dy == 0) {
+                    const TwoPairs lr = lds_quad_at(lds, cb + 0 * C::PLANE), gv = lds_quad_at(lds, cb + 1 * C::PLANE);
+                    tap_center<f2>(acc, lr.a, lr.b, gv.a, gv.b);
+                    return;
+                }
+                f2 e0 = splat(kLogB3[adx] + kLogB3[ady], f2{});
+                if (ZA) {
+                    bool okA = rowv[dy + 2], okB = okA;
+                    if (XE) {
+                        okA = okA && xA + dx * S >= 0 && xA + dx * S < g.W;
+                        okB = okB && xA + 1 + dx * S >= 0 && xA + 1 + dx * S < g.W;
+                    }
+                    e0 = f2{ okA ? e0.x : kNegInf, okB ? e0.y : kNegInf };
+                }
+                tap_eval<f2, ZA>(acc, k, tp, e0, len_class(adx, ady), sn2);
+            };
+            TapT<f2> t0, t1;
+            load_tap(0, t0);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int ti = i < 12 ? i : i + 1, tn = i + 1 < 12 ? i + 1 : i + 2;
+                if (i == 12) weigh(12, t0);
+                if (i < 23) { if (i & 1) load_tap(tn, t0); else load_tap(tn, t1); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (i & 1) weigh(ti, t1); else weigh(ti, t0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
+        const TwoPairs flr = lds_quad_at(lds, cb + 0 * C::PLANE), fgv = lds_quad_at(lds, cb + 1 * C::PLANE);
+        const float4 outA = finish2(acc.sw.x, acc.sl.x, acc.sr.x, acc.sg.x, acc.sv.x, flr.a.x, flr.b.x, fgv.a.x, fgv.b.x);
+        const float4 outB = finish2(acc.sw.y, acc.sl.y, acc.sr.y, acc.sg.y, acc.sv.y, flr.a.y, flr.b.y, fgv.a.y, fgv.b.y);
+        // every LDS read of this step has returned (its value was used): the slots may be recycled
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (lane == 0) flags[4 + wv] = t + 1;
+        RMD_PHASE(1)
+        store_aux();
+#ifdef RMD_LC_ABL_NOOUT
+        if (outA.x + outB.x == -12345.678f)
+#endif
+        if (jw >= jlo && jw < jhi) {
+            float4* o = a.out + (size_t)(y - g.buf_row0) * (size_t)g.W + (size_t)xA;
+            if (inA) o[0] = outA;
+            if (inB) o[1] = outB;
+        }
+        RMD_PHASE(2)
+    }
+#ifdef RMD_ATROUS_TRACE
+    if (lane == 0 && blockIdx.x < 8192 && (wv == 0 || wv == L::NC - 1)) {
+        if (wv == 0) for (int i = 0; i < 3; ++i) g_atrous_phase[8 * blockIdx.x + i] = ph[i];
+        else         for (int i = 0; i < 2; ++i) g_atrous_phase[8 * blockIdx.x + 3 + i] = ph[i];
+    }
+#endif
+}
+
+template <int S>
+__global__ __launch_bounds__(LcCfg<S>::THREADS, 4) void atrous_lc_kernel(AtrousArgs a)
+{
+    using C = PairCfg<S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char atrous_lds[];
+    const int tid = threadIdx.x;
+    const int pid = blockIdx.x;
+    const int xcd = pid & (kXcds - 1), slot = pid >> 3;
+    int L;
+    if (slot < a.int_per_xcd) { L = xcd * a.int_per_xcd + slot; if (L >= a.total_int) return; }
+    else { L = a.total_int + xcd * a.xe_per_xcd + (slot - a.int_per_xcd); if (L >= a.nblocks) return; }
+    int strip, band, r, bh;
+    if (L < a.total_int) {
+        r = L % S; const int t = L / S;
+        strip = a.xe_lo + t % a.n_int; band = t / a.n_int; bh = a.band_h;
+    } else {
+        const int Lx = L - a.total_int, nxe = a.nstrips - a.n_int;
+        r = Lx % S; const int t = Lx / S, e = t % nxe;
+        strip = e < a.xe_lo ? e : a.n_int + e; band = t / nxe; bh = a.band_h_xe;
+    }
+    const int x0 = strip * C::CW;
+    const int yb = a.band_base + band * bh;
+    const int lo = max(yb, a.row0), hi = min(yb + bh, a.row1);
+    const int ybase = yb + r;
+    const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
+    const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;
+    if (jlo >= jhi) return;
+    const bool xedge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W);
+#ifdef RMD_ATROUS_TRACE
+    const unsigned long long trace_t0 = wall_clock64(), trace_c0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (xedge) atrous_lc_body<S, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+    else       atrous_lc_body<S, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+#ifdef RMD_ATROUS_TRACE
+    __syncthreads();
+    if (tid == 0 && pid < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_atrous_trace[6 * pid + 0] = trace_t0;
+        g_atrous_trace[6 * pid + 1] = wall_clock64();
+        g_atrous_trace[6 * pid + 2] = ((unsigned long long)xcc << 32) | hw;
+        g_atrous_trace[6 * pid + 3] = ((unsigned long long)L << 8) | (xedge ? 1u : 0u);
+        g_atrous_trace[6 * pid + 4] = __builtin_amdgcn_s_memtime() - trace_c0;
+        g_atrous_trace[6 * pid + 5] = (unsigned long long)(jhi - jlo);
+    }
+#endif
+}
+
+template <int S, bool LC = false>
 static int launch_pair(AtrousArgs a, hipStream_t stream)
 {
     using C = PairCfg<S>;
-    if (first_use_on_device(reinterpret_cast<const void*>(&atrous_pair_kernel<S>)))
-        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_pair_kernel<S>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+    const void* fn = LC ? reinterpret_cast<const void*>(&atrous_lc_kernel<S>) : reinterpret_cast<const void*>(&atrous_pair_kernel<S>);
+    constexpr int lds_bytes = LC ? LcCfg<S>::LDS_BYTES : C::LDS_BYTES;
+    if (first_use_on_device(fn))
+        RMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     a.band_base = a.row0 / (4 * S) * (4 * S);
     const int rows = a.row1 - a.band_base;
     a.nstrips = (a.g.W + C::CW - 1) / C::CW;
@@ -1416,8 +1863,8 @@ static int launch_pair(AtrousArgs a, hipStream_t stream)
     // slower), so the launch runs in ceil(workgroups / resident slots) rounds; take the band count that
     // fills the rounds best, discounted by the 4 halo rows a workgroup stages on top of its own rows.
     // (3840 wide: 28 interior + 2 border strips = 32 S b workgroups, i.e. exactly 768 for S <= 8.)
-    const int unit = S * C::ADV;
-    const int slots = C::WG_PER_CU * device_cus();
+    const int unit = S * (LC ? LcCfg<S>::NC : C::ADV);
+    const int slots = (LC ? LcCfg<S>::WG_PER_CU : C::WG_PER_CU) * device_cus();
     int best_nb = 1;
     double best = -1.0;
     for (int nb = 1; nb <= 64; ++nb) {
@@ -1443,9 +1890,21 @@ static int launch_pair(AtrousArgs a, hipStream_t stream)
     a.int_per_xcd = (a.total_int + kXcds - 1) / kXcds;
     a.xe_per_xcd = (a.nblocks - a.total_int + kXcds - 1) / kXcds;
     a.per_xcd = a.int_per_xcd + a.xe_per_xcd;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_pair_kernel<S>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES, stream, a);
+    if (LC) hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_lc_kernel<S>), dim3(a.per_xcd * kXcds), dim3(LcCfg<S>::THREADS), lds_bytes, stream, a);
+    else    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_pair_kernel<S>), dim3(a.per_xcd * kXcds), dim3(256), lds_bytes, stream, a);
     RMD_LAUNCH_CHECK("atrous_pair_kernel");
     return RMD_OK;
+}
+
+static int launch_lc_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
+{
+    switch (iteration) {
+        case 0: return launch_pair<1, true>(a, stream);
+        case 1: return launch_pair<2, true>(a, stream);
+        case 2: return launch_pair<4, true>(a, stream);
+        case 3: return launch_pair<8, true>(a, stream);
+        default: return launch_pair<16, true>(a, stream);
+    }
 }
 
 static int launch_pair_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
@@ -1563,6 +2022,13 @@ static int launch_stream_auto_iter(int iteration, const AtrousArgs& a, hipStream
 
 using namespace rmd;
 
+extern "C" int rmd_debug_atrous_protocol_errors(unsigned int* count)
+{
+    if (!count) return fail(RMD_E_NULL, "rmd_debug_atrous_protocol_errors: count is NULL");
+    RMD_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_atrous_lc_errors), sizeof(unsigned int)));
+    return RMD_OK;
+}
+
 extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
                                const float* in, float* out, int row0, int row1, void* stream)
 {
@@ -1598,6 +2064,10 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     if (variant == 4) {
         if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
         return launch_pair_iter(iteration, a, as_stream(stream));                       // pixel pairs, SoA LDS planes
+    }
+    if (variant == 7) {
+        if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
+        return launch_lc_iter(iteration, a, as_stream(stream));                         // pixel pairs, loader wave + 4 compute waves
     }
     if (variant == 5) {
         dim3 grid5((f->width + 63) / 64, (row1 - row0 + 3) / 4);

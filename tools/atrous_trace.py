@@ -40,7 +40,14 @@ for it in range(5):
         phs = buf[NWG * 6:].reshape(NWG, 8)[rec[:, 0] > 0][:, :5].astype(np.float64)
         tot = phs.sum(axis=1, keepdims=True)
         frac = np.median(phs / np.maximum(tot, 1), axis=0)
-        print("    wave-0 time split (median over workgroups): issue loads %.3f  compute %.3f  barrier1 %.3f  store %.3f  barrier2 %.3f" % tuple(frac))
+        if p.atrous_variant == 7:      # loader/consumer kernel: cycles, not fractions
+            ph8 = buf[NWG * 6:].reshape(NWG, 8)[rec[:, 0] > 0].astype(np.float64)
+            rows8 = np.maximum(rec[rec[:, 0] > 0][:, 5].astype(np.float64), 1)
+            med = np.median(ph8 / rows8[:, None], axis=0) * 12
+            print("    cycles per step (12 lattice rows), median: consumer 0 wait %.0f compute %.0f loads+stores %.0f | consumer 11 wait %.0f compute %.0f"
+                  " | loader wait-for-slot %.0f commit %.0f issue %.0f" % tuple(med))
+        else:
+            print("    wave-0 time split (median over workgroups): issue loads %.3f  compute %.3f  barrier1 %.3f  store %.3f  barrier2 %.3f" % tuple(frac))
     t = rec[rec[:, 0] > 0]
     t0 = t[:, 0].min()
     start, end = (t[:, 0] - t0).astype(np.int64), (t[:, 1] - t0).astype(np.int64)
@@ -71,5 +78,5 @@ for it in range(5):
     sel = ~edge
     print(f"    shader clock while resident: p50 {np.percentile(ghz, 50):.2f} GHz (p10 {np.percentile(ghz, 10):.2f}, p90 {np.percentile(ghz, 90):.2f}); "
           f"interior workgroups: {np.percentile(cyc[sel] / rows[sel], 50):.0f} cycles per lattice row of 128 px (p90 {np.percentile(cyc[sel] / rows[sel], 90):.0f})")
-    occ = (dur.sum() / max(end.max(), 1)) / (len(per_cu) * 3)
-    print(f"    average resident workgroups / (CUs x 3): {occ:.3f}")
+    occ = (dur.sum() / max(end.max(), 1)) / (len(per_cu) * (1 if p.atrous_variant == 7 else 3))
+    print(f"    average resident workgroups / (CUs x slots per CU): {occ:.3f}")
