@@ -139,9 +139,10 @@ typedef struct rmd_svgf_params {
     int   atrous_variant;   /* 0 auto (= 3 for iterations 0..4, 1 beyond) | row-pair formulation: 1 direct (taps from global memory, any step),
                                    2 / 3 / 6 LDS row streaming with one / two / four row pairs per workgroup |
                                    pixel-pair formulation: 4 LDS row streaming, 5 direct, 7 LDS row streaming with
-                                   loader waves feeding compute waves through counters instead of barriers
-                                   (experiment, slower: DESIGN.md §4.6).  0, 1, 2, 3, 6 give identical bits, so do
-                                   4, 5 and 7 (the two families differ in the order of summation, i.e. by rounding) */
+                                   loader waves feeding compute waves through counters instead of barriers, 8 LDS
+                                   row streaming with a 2x2 pixel block per lane (7 and 8 are measured experiments,
+                                   slower: DESIGN.md §4.6, §4.7).  0, 1, 2, 3, 6 give identical bits, so do 4, 5, 7
+                                   and 8 (the two families differ in the order of summation, i.e. by rounding)   */
     int   tv_workgroups;    /* 0   T and V as one workgroup per 64x4 tile (default, fastest) | N > 0: N persistent
                                    workgroups that walk the tiles: a constant register footprint beside another
                                    frame's a-trous launches (experimental, slower so far); same results either way */

@@ -1395,6 +1395,356 @@ __global__ __launch_bounds__(256, 3) void atrous_pair_kernel(AtrousArgs a)
 #endif
 }
 
+// ------------------------------------------------------------------------- 2 x 2 pixel block per lane (variant 8)
+// The pixel-pair arithmetic with TWO output rows per wave: a lane owns pixels (xA, xA+1) of lattice rows jw and
+// jw+1, walks the 5 x 6 tap positions both rows see and weighs each position for the rows that tap it (rows 1..4
+// of the window for both, row 0 for the upper and row 5 for the lower output only).  One position is four
+// ds_read_b128 as before, so an output costs 480 instead of 800 bytes of LDS reads with every instruction still
+// packed (the row-pair kernel has the same LDS ratio but weighs its rows 0 and 5 unpacked).  A step yields 8
+// lattice rows from a ring of 12; that is 59-70 KB of LDS, i.e. two workgroups = 2 waves per SIMD with up to
+// 256 VGPRs each, which the two independent accumulator sets and the refill registers (12 + 16 loads in flight
+// per lane) use.  Same per-output operation order as atrous_direct2_kernel: identical bits.
+template <int S>
+struct QuadCfg {
+    using P = PairCfg<S>;
+    static constexpr int ADV = 8, NR = 12;           // ring rows j-2 .. j+9; a step yields rows j .. j+7 (two per wave)
+    static constexpr int RING_BYTES = NR * P::ROW_BYTES;
+    static constexpr int AUX_OFF = RING_BYTES;       // per output row of the step: var(y-1), var(y+1)
+    static constexpr int LDS_BYTES = AUX_OFF + ADV * 2 * P::AUX_ROW;
+    static constexpr int WG_PER_CU = 2 * LDS_BYTES <= 160 * 1024 ? 2 : 1;
+};
+
+template <int S, bool XE>
+__device__ __forceinline__ void atrous_quad_body(const AtrousArgs& a, unsigned char* lds, const int tid,
+                                                 const int x0, const int ybase, const int jlo, const int jhi)
+{
+    using C = PairCfg<S>;
+    using Q = QuadCfg<S>;
+    const Geom g = a.g;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave -> output rows j + 2 wv, j + 2 wv + 1 of the step
+    const int xA = x0 + 2 * lane;
+    const bool inA = !XE || xA < g.W, inB = !XE || xA + 1 < g.W;
+    const float* in_f = reinterpret_cast<const float*>(a.in);
+    const float* nd_f = reinterpret_cast<const float*>(a.nd);
+    const int blo = max(g.buf_row0, 0), bhi = min(g.buf_row0 + g.buf_rows, g.H);
+
+    auto slot_of = [&](const int j) { return (j + 4 * Q::NR) % Q::NR; };        // j >= -2
+
+    // ---- staging (as in the pixel-pair kernel; a wave stages the two rows jb + 2 wv, jb + 2 wv + 1 of a refill)
+    int gofs[3], sofs[3];
+    float keepx[3];
+    bool sact[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int col = lane + 64 * q;
+        sact[q] = col < C::PW;
+        const int colc = min(col, C::PW - 1);
+        const int gx = x0 - 2 * S + colc;
+        keepx[q] = (!XE || (gx >= 0 && gx < g.W)) ? 1.0f : 0.0f;
+        gofs[q] = XE ? min(max(gx, 0), g.W - 1) : gx;
+        sofs[q] = (colc >> 1) * 16 + (colc & 1) * 4;
+    }
+    float4 pc[2][3], pn[2][3];
+    bool prow_ok[2] = { true, true };
+    const float4 *prc[2] = { a.in, a.in }, *prn[2] = { a.nd, a.nd };
+    auto begin_rows = [&](const int jb) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = ybase + (jb + 2 * wv + r) * S;
+            prow_ok[r] = y >= blo && y < bhi;
+            const int yc = min(max(y, blo), bhi - 1);
+            prc[r] = a.in + (size_t)(yc - g.buf_row0) * (size_t)g.W;
+            prn[r] = a.nd + (size_t)(yc - g.buf_row0) * (size_t)g.W;
+        }
+    };
+    auto load_rows_piece = [&](const int i) {      // i = 0..11: one vector-memory instruction each
+        const int r = i / 6, ii = i % 6;
+        if (ii & 1) pn[r][ii >> 1] = prn[r][gofs[ii >> 1]]; else pc[r][ii >> 1] = prc[r][gofs[ii >> 1]];
+    };
+    auto store_rows = [&](const int jb) {
+        constexpr int PF = C::PLANE / 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            unsigned char* row = lds + slot_of(jb + 2 * wv + r) * C::ROW_BYTES;
+            const float krow = prow_ok[r] ? 1.0f : 0.0f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (sact[q]) {
+                    float* p = reinterpret_cast<float*>(row + sofs[q]);
+                    float nx = pn[r][q].x, ny = pn[r][q].y, nz = pn[r][q].z;
+                    if (XE || !prow_ok[r]) { const float kk = XE ? krow * keepx[q] : krow; nx *= kk; ny *= kk; nz *= kk; }
+                    p[0 * PF] = lum3(pc[r][q].x, pc[r][q].y, pc[r][q].z); p[0 * PF + 2] = pc[r][q].x;
+                    p[1 * PF] = pc[r][q].y;                                p[1 * PF + 2] = pc[r][q].w;
+                    p[2 * PF] = nx;                                        p[2 * PF + 2] = ny;
+                    p[3 * PF] = nz;                                        p[3 * PF + 2] = pn[r][q].w;
+                }
+            }
+        }
+    };
+    int aofs[3], zofs[2];
+    {
+        const int g0 = x0 - 2 + lane, g1 = g0 + 64, g2 = x0 + C::CW - 2 + (lane & 3);
+        aofs[0] = (XE ? min(max(g0, 0), g.W - 1) : g0) * 4 + 3;
+        aofs[1] = (XE ? min(max(g1, 0), g.W - 1) : g1) * 4 + 3;
+        aofs[2] = (XE ? min(max(g2, 0), g.W - 1) : g2) * 4 + 3;
+        zofs[0] = (XE ? min(xA, g.W - 1) : xA) * 4 + 3;
+        zofs[1] = (XE ? min(xA + 1, g.W - 1) : xA + 1) * 4 + 3;
+    }
+    float pau[2][2][2], pax[2][2];                 // [output row][...]
+    f2 zd_cur[2] = { f2{ 0.0f, 0.0f }, f2{ 0.0f, 0.0f } }, zd_next[2] = { zd_cur[0], zd_cur[0] };
+    const float *pup[2] = { in_f, in_f }, *pdn[2] = { in_f, in_f }, *pzr[2] = { nd_f, nd_f };
+    auto begin_aux = [&](const int jo) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int y = min(max(ybase + (jo + 2 * wv + r) * S, blo), bhi - 1);
+            const int yu = max(y - 1, blo), yd = min(y + 1, bhi - 1);
+            pup[r] = in_f + (size_t)(yu - g.buf_row0) * (size_t)g.W * 4;
+            pdn[r] = in_f + (size_t)(yd - g.buf_row0) * (size_t)g.W * 4;
+            pzr[r] = nd_f + (size_t)(yd - g.buf_row0) * (size_t)g.W * 4;
+        }
+    };
+    auto load_aux_piece = [&](const int i) {       // i = 0..15: one vector-memory instruction each
+        const int r = i / 8;
+        switch (i % 8) {
+            case 0: pau[r][0][0] = pup[r][aofs[0]]; break;
+            case 1: pau[r][1][0] = pup[r][aofs[1]]; break;
+            case 2: pax[r][0] = pup[r][aofs[2]]; break;
+            case 3: pau[r][0][1] = pdn[r][aofs[0]]; break;
+            case 4: pau[r][1][1] = pdn[r][aofs[1]]; break;
+            case 5: pax[r][1] = pdn[r][aofs[2]]; break;
+            case 6: zd_next[r].x = pzr[r][zofs[0]]; break;
+            default: zd_next[r].y = pzr[r][zofs[1]]; break;
+        }
+    };
+    auto store_aux = [&]() {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            float* ax = reinterpret_cast<float*>(lds + Q::AUX_OFF + (2 * wv + r) * 2 * C::AUX_ROW);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                ax[k * C::AUXW + lane] = pau[r][0][k];
+                ax[k * C::AUXW + 64 + lane] = pau[r][1][k];
+                if (lane < 4) ax[k * C::AUXW + C::CW + lane] = pax[r][k];
+            }
+            zd_cur[r] = zd_next[r];
+        }
+    };
+
+    float4 out[2][2];                              // [output row][pixel]
+    auto compute = [&](const int j) {
+        const int jw = j + 2 * wv;                 // upper output row; the lower one is jw + 1
+        const int y0 = ybase + jw * S;
+        begin_rows(j + 10);
+        begin_aux(j + Q::ADV);
+        int rb[6];                                 // window rows jw-2 .. jw+3
+#pragma unroll
+        for (int tr = 0; tr < 6; ++tr) rb[tr] = slot_of(jw - 2 + tr) * C::ROW_BYTES + (S + lane) * 16;
+        CenterT<f2> k[2];
+        bool zero[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int cb = rb[2 + r];
+            const int y = y0 + r * S;
+            const f2 cv = lds_f2(lds, cb + 1 * C::PLANE + 8);
+            { const TwoPairs q = lds_quad_at(lds, cb + 2 * C::PLANE); k[r].nx = q.a; k[r].ny = q.b; }
+            { const TwoPairs q = lds_quad_at(lds, cb + 3 * C::PLANE); k[r].nz = q.a; k[r].z = q.b; }
+            k[r].l = lds_f2(lds, cb + 0 * C::PLANE);
+            const bool zA = k[r].nx.x == 0.0f && k[r].ny.x == 0.0f && k[r].nz.x == 0.0f;
+            const bool zB = k[r].nx.y == 0.0f && k[r].ny.y == 0.0f && k[r].nz.y == 0.0f;
+            k[r].zc = f2{ zA ? 1.0f : 0.0f, zB ? 1.0f : 0.0f };
+            zero[r] = (zA && inA) || (zB && inB);
+            const unsigned char* axb = lds + Q::AUX_OFF + (2 * wv + r) * 2 * C::AUX_ROW + lane * 8;
+            const f2 vu_l = lds_f2u(axb, 0 * C::AUX_ROW + 4), vu_c = lds_f2(axb, 0 * C::AUX_ROW + 8), vu_r = lds_f2u(axb, 0 * C::AUX_ROW + 12);
+            const f2 vd_l = lds_f2u(axb, 1 * C::AUX_ROW + 4), vd_c = lds_f2(axb, 1 * C::AUX_ROW + 8), vd_r = lds_f2u(axb, 1 * C::AUX_ROW + 12);
+            const f2 vm_l = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 - 12), vm_r = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 + 4);
+            f2 zr = lds_odd_pair(lds, cb + 3 * C::PLANE + 8 + 4);
+            const f2 zd = zd_cur[r];
+            const bool oku = y - 1 >= 0, okd = y + 1 < g.H;
+            f2 var_c;
+            if (!XE && oku && okd) {
+                f2 v = splat(0.0625f, f2{}) * vu_l;
+                v = fma_(splat(0.125f, f2{}), vm_l, v);  v = fma_(splat(0.0625f, f2{}), vd_l, v);
+                v = fma_(splat(0.125f, f2{}), vu_c, v);  v = fma_(splat(0.25f, f2{}), cv, v);   v = fma_(splat(0.125f, f2{}), vd_c, v);
+                v = fma_(splat(0.0625f, f2{}), vu_r, v); v = fma_(splat(0.125f, f2{}), vm_r, v); v = fma_(splat(0.0625f, f2{}), vd_r, v);
+                var_c = v;
+            } else {
+                float vcs[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int x = xA + i;
+                    const bool okl = !XE || x - 1 >= 0, okr = !XE || x + 1 < g.W;
+                    const float ul = i ? vu_l.y : vu_l.x, uc = i ? vu_c.y : vu_c.x, ur = i ? vu_r.y : vu_r.x;
+                    const float dl = i ? vd_l.y : vd_l.x, dc = i ? vd_c.y : vd_c.x, dr = i ? vd_r.y : vd_r.x;
+                    const float ml = i ? vm_l.y : vm_l.x, mr = i ? vm_r.y : vm_r.x, mc = i ? cv.y : cv.x;
+                    if (okl && okr && oku && okd) { vcs[i] = prefilter9(ul, ml, dl, uc, mc, dc, ur, mr, dr); continue; }
+                    float gs = 0.25f, vs = 0.25f * mc;
+                    if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, ul, vs); }
+                    if (okl)        { gs += 0.125f;  vs = fma_(0.125f, ml, vs); }
+                    if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, dl, vs); }
+                    if (oku)        { gs += 0.125f;  vs = fma_(0.125f, uc, vs); }
+                    if (okd)        { gs += 0.125f;  vs = fma_(0.125f, dc, vs); }
+                    if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, ur, vs); }
+                    if (okr)        { gs += 0.125f;  vs = fma_(0.125f, mr, vs); }
+                    if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, dr, vs); }
+                    vcs[i] = vs / gs;
+                }
+                var_c = f2{ vcs[0], vcs[1] };
+            }
+            if (XE) {
+                if (xA + 1 >= g.W) zr.x = k[r].z.x;
+                if (xA + 2 >= g.W) zr.y = k[r].z.y;
+            }
+            const f2 gz = f2{ fabsf(zr.x - k[r].z.x) + fabsf(zd.x - k[r].z.x), fabsf(zr.y - k[r].z.y) + fabsf(zd.y - k[r].z.y) };
+            center_consts<f2>(k[r], var_c, gz, a.sigma_z, a.sigma_l, (float)S);
+        }
+        bool rowv[6];
+#pragma unroll
+        for (int tr = 0; tr < 6; ++tr) {
+            const int yy = y0 + (tr - 2) * S;
+            rowv[tr] = yy >= 0 && yy < g.H;
+        }
+        const bool any_zero = __builtin_amdgcn_ballot_w64(zero[0] || zero[1]) != 0ull;
+        float sn = a.sigma_n;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));
+        const f2 sn2 = splat(sn, f2{});
+        AccT<f2> acc[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[r] = AccT<f2>{ f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
+
+        auto load_pos = [&](const int pi, TapT<f2>& t) {          // position = (column offset, window row)
+            const int dxi = pi / 6, tr = pi % 6;
+            const int sdx = (dxi - 2) * S;
+            if ((sdx & 1) == 0) {
+                const int off = rb[tr] + (sdx / 2) * 16;
+                { const TwoPairs q = lds_quad_at(lds, off + 0 * C::PLANE); t.l = q.a; t.r = q.b; }
+                { const TwoPairs q = lds_quad_at(lds, off + 1 * C::PLANE); t.g = q.a; t.v = q.b; }
+                { const TwoPairs q = lds_quad_at(lds, off + 2 * C::PLANE); t.nx = q.a; t.ny = q.b; }
+                { const TwoPairs q = lds_quad_at(lds, off + 3 * C::PLANE); t.nz = q.a; t.z = q.b; }
+            } else {
+                const int off = rb[tr] + ((sdx - 1) / 2) * 16 + 4;
+                t.l = lds_odd_pair(lds, off + 0 * C::PLANE);  t.r = lds_odd_pair(lds, off + 0 * C::PLANE + 8);
+                t.g = lds_odd_pair(lds, off + 1 * C::PLANE);  t.v = lds_odd_pair(lds, off + 1 * C::PLANE + 8);
+                t.nx = lds_odd_pair(lds, off + 2 * C::PLANE); t.ny = lds_odd_pair(lds, off + 2 * C::PLANE + 8);
+                t.nz = lds_odd_pair(lds, off + 3 * C::PLANE); t.z = lds_odd_pair(lds, off + 3 * C::PLANE + 8);
+            }
+        };
+        auto taps = [&](auto zero_aware) {
+            constexpr bool ZA = decltype(zero_aware)::value;
+            auto weigh = [&](const int pi, const TapT<f2>& t) {
+                const int dx = pi / 6 - 2, tr = pi % 6;
+                const int adx = dx < 0 ? -dx : dx;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int dy = tr - 2 - r;
+                    if (dy < -2 || dy > 2) continue;
+                    const int ady = dy < 0 ? -dy : dy;
+                    if (dx == 0 && dy == 0) { tap_center<f2>(acc[r], t.l, t.r, t.g, t.v); continue; }
+                    f2 e0 = splat(kLogB3[adx] + kLogB3[ady], f2{});
+                    if (ZA) {
+                        bool okA = rowv[tr], okB = okA;
+                        if (XE) {
+                            okA = okA && xA + dx * S >= 0 && xA + dx * S < g.W;
+                            okB = okB && xA + 1 + dx * S >= 0 && xA + 1 + dx * S < g.W;
+                        }
+                        e0 = f2{ okA ? e0.x : kNegInf, okB ? e0.y : kNegInf };
+                    }
+                    tap_eval<f2, ZA>(acc[r], k[r], t, e0, len_class(adx, ady), sn2);
+                }
+            };
+            // 30 positions, dx outer / window row inner (each output sees its 25 taps in dx-outer / dy-inner order),
+            // double-buffered; the 28 vector-memory instructions of the next refill go out one per position
+            TapT<f2> t0, t1;
+            load_pos(0, t0);
+#pragma unroll
+            for (int q = 0; q < 30; ++q) {
+                if (q < 29) { if (q & 1) load_pos(q + 1, t0); else load_pos(q + 1, t1); }
+                if (q < 12) load_rows_piece(q); else if (q < 28) load_aux_piece(q - 12);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q & 1) weigh(q, t1); else weigh(q, t0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int cb = rb[2 + r];
+            const TwoPairs flr = lds_quad_at(lds, cb + 0 * C::PLANE), fgv = lds_quad_at(lds, cb + 1 * C::PLANE);
+            out[r][0] = finish2(acc[r].sw.x, acc[r].sl.x, acc[r].sr.x, acc[r].sg.x, acc[r].sv.x, flr.a.x, flr.b.x, fgv.a.x, fgv.b.x);
+            out[r][1] = finish2(acc[r].sw.y, acc[r].sl.y, acc[r].sr.y, acc[r].sg.y, acc[r].sv.y, flr.a.y, flr.b.y, fgv.a.y, fgv.b.y);
+        }
+    };
+    auto write_out = [&](const int j) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int jw = j + 2 * wv + r;
+            if (jw >= jlo && jw < jhi) {
+                float4* o = a.out + (size_t)(ybase + jw * S - g.buf_row0) * (size_t)g.W + (size_t)xA;
+                if (inA) o[0] = out[r][0];
+                if (inB) o[1] = out[r][1];
+            }
+        }
+    };
+
+    // ---- prologue: ring rows j0-2 .. j0+9 (one and a half refills) and the aux rows of the first step
+    const int j0 = jlo & ~7;
+    begin_rows(j0 - 2);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_rows_piece(i);
+    store_rows(j0 - 2);
+    begin_rows(j0 + 6);                            // rows j0+6 .. j0+13: only j0+6 .. j0+9 (waves 0, 1) belong to the first window
+#pragma unroll
+    for (int i = 0; i < 12; ++i) load_rows_piece(i);
+    begin_aux(j0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) load_aux_piece(i);
+    if (wv < 2) store_rows(j0 + 6);
+    store_aux();
+    __syncthreads();
+
+    for (int j = j0; j < jhi; j += Q::ADV) {
+        const bool more = j + Q::ADV < jhi;
+        compute(j);
+        if (!more) { write_out(j); break; }
+        __syncthreads();                           // every wave is done reading rows j-2 .. j+5 and the aux rows
+        store_rows(j + 10); store_aux();
+        write_out(j);
+        __syncthreads();
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256, 2) void atrous_quad_kernel(AtrousArgs a)
+{
+    using C = PairCfg<S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char atrous_lds[];
+    const int tid = threadIdx.x;
+    const int pid = blockIdx.x;
+    const int xcd = pid & (kXcds - 1), slot = pid >> 3;
+    int L;
+    if (slot < a.int_per_xcd) { L = xcd * a.int_per_xcd + slot; if (L >= a.total_int) return; }
+    else { L = a.total_int + xcd * a.xe_per_xcd + (slot - a.int_per_xcd); if (L >= a.nblocks) return; }
+    int strip, band, r, bh;
+    if (L < a.total_int) {
+        r = L % S; const int t = L / S;
+        strip = a.xe_lo + t % a.n_int; band = t / a.n_int; bh = a.band_h;
+    } else {
+        const int Lx = L - a.total_int, nxe = a.nstrips - a.n_int;
+        r = Lx % S; const int t = Lx / S, e = t % nxe;
+        strip = e < a.xe_lo ? e : a.n_int + e; band = t / nxe; bh = a.band_h_xe;
+    }
+    const int x0 = strip * C::CW;
+    const int yb = a.band_base + band * bh;
+    const int lo = max(yb, a.row0), hi = min(yb + bh, a.row1);
+    const int ybase = yb + r;
+    const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
+    const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;
+    if (jlo >= jhi) return;
+    const bool xedge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W);
+    if (xedge) atrous_quad_body<S, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+    else       atrous_quad_body<S, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+}
+
 // ------------------------------------------------------------------------- loader / consumer form
 // The pixel-pair arithmetic with staging taken out of the compute waves (variant 7).  The ablations of the two
 // kernels above say a step is a chain -- refill loads, 25 x [LDS reads, arithmetic], barrier, LDS stores,
@@ -1841,15 +2191,17 @@ __global__ __launch_bounds__(LcCfg<S>::THREADS, 4) void atrous_lc_kernel(AtrousA
 #endif
 }
 
-template <int S, bool LC = false>
+template <int S, int MODE = 0>                      // 0 pixel-pair (barriers), 1 loader/consumer, 2 quad (2 x 2 block per lane)
 static int launch_pair(AtrousArgs a, hipStream_t stream)
 {
     using C = PairCfg<S>;
-    const void* fn = LC ? reinterpret_cast<const void*>(&atrous_lc_kernel<S>) : reinterpret_cast<const void*>(&atrous_pair_kernel<S>);
-    constexpr int lds_bytes = LC ? LcCfg<S>::LDS_BYTES : C::LDS_BYTES;
+    constexpr bool LC = MODE == 1, QD = MODE == 2;
+    const void* fn = LC ? reinterpret_cast<const void*>(&atrous_lc_kernel<S>)
+                   : QD ? reinterpret_cast<const void*>(&atrous_quad_kernel<S>) : reinterpret_cast<const void*>(&atrous_pair_kernel<S>);
+    constexpr int lds_bytes = LC ? LcCfg<S>::LDS_BYTES : QD ? QuadCfg<S>::LDS_BYTES : C::LDS_BYTES;
     if (first_use_on_device(fn))
         RMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    a.band_base = a.row0 / (4 * S) * (4 * S);
+    a.band_base = a.row0 / (8 * S) * (8 * S);
     const int rows = a.row1 - a.band_base;
     a.nstrips = (a.g.W + C::CW - 1) / C::CW;
     // strips whose staged columns leave the frame (same test as the kernel's)
@@ -1863,8 +2215,8 @@ static int launch_pair(AtrousArgs a, hipStream_t stream)
     // slower), so the launch runs in ceil(workgroups / resident slots) rounds; take the band count that
     // fills the rounds best, discounted by the 4 halo rows a workgroup stages on top of its own rows.
     // (3840 wide: 28 interior + 2 border strips = 32 S b workgroups, i.e. exactly 768 for S <= 8.)
-    const int unit = S * (LC ? LcCfg<S>::NC : C::ADV);
-    const int slots = (LC ? LcCfg<S>::WG_PER_CU : C::WG_PER_CU) * device_cus();
+    const int unit = S * (LC ? LcCfg<S>::NC : QD ? QuadCfg<S>::ADV : C::ADV);
+    const int slots = (LC ? LcCfg<S>::WG_PER_CU : QD ? QuadCfg<S>::WG_PER_CU : C::WG_PER_CU) * device_cus();
     int best_nb = 1;
     double best = -1.0;
     for (int nb = 1; nb <= 64; ++nb) {
@@ -1890,8 +2242,9 @@ static int launch_pair(AtrousArgs a, hipStream_t stream)
     a.int_per_xcd = (a.total_int + kXcds - 1) / kXcds;
     a.xe_per_xcd = (a.nblocks - a.total_int + kXcds - 1) / kXcds;
     a.per_xcd = a.int_per_xcd + a.xe_per_xcd;
-    if (LC) hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_lc_kernel<S>), dim3(a.per_xcd * kXcds), dim3(LcCfg<S>::THREADS), lds_bytes, stream, a);
-    else    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_pair_kernel<S>), dim3(a.per_xcd * kXcds), dim3(256), lds_bytes, stream, a);
+    if (LC)      hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_lc_kernel<S>), dim3(a.per_xcd * kXcds), dim3(LcCfg<S>::THREADS), lds_bytes, stream, a);
+    else if (QD) hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_quad_kernel<S>), dim3(a.per_xcd * kXcds), dim3(256), lds_bytes, stream, a);
+    else         hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_pair_kernel<S>), dim3(a.per_xcd * kXcds), dim3(256), lds_bytes, stream, a);
     RMD_LAUNCH_CHECK("atrous_pair_kernel");
     return RMD_OK;
 }
@@ -1899,11 +2252,22 @@ static int launch_pair(AtrousArgs a, hipStream_t stream)
 static int launch_lc_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
 {
     switch (iteration) {
-        case 0: return launch_pair<1, true>(a, stream);
-        case 1: return launch_pair<2, true>(a, stream);
-        case 2: return launch_pair<4, true>(a, stream);
-        case 3: return launch_pair<8, true>(a, stream);
-        default: return launch_pair<16, true>(a, stream);
+        case 0: return launch_pair<1, 1>(a, stream);
+        case 1: return launch_pair<2, 1>(a, stream);
+        case 2: return launch_pair<4, 1>(a, stream);
+        case 3: return launch_pair<8, 1>(a, stream);
+        default: return launch_pair<16, 1>(a, stream);
+    }
+}
+
+static int launch_quad_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
+{
+    switch (iteration) {
+        case 0: return launch_pair<1, 2>(a, stream);
+        case 1: return launch_pair<2, 2>(a, stream);
+        case 2: return launch_pair<4, 2>(a, stream);
+        case 3: return launch_pair<8, 2>(a, stream);
+        default: return launch_pair<16, 2>(a, stream);
     }
 }
 
@@ -2068,6 +2432,10 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     if (variant == 7) {
         if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
         return launch_lc_iter(iteration, a, as_stream(stream));                         // pixel pairs, loader wave + 4 compute waves
+    }
+    if (variant == 8) {
+        if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
+        return launch_quad_iter(iteration, a, as_stream(stream));                       // 2 x 2 pixel block per lane
     }
     if (variant == 5) {
         dim3 grid5((f->width + 63) / 64, (row1 - row0 + 3) / 4);

@@ -104,7 +104,7 @@ def test_variance_parity(rmd, orc, cuda, width, height):
         assert abs(s[0] - fr.v_color[..., 3].sum()) <= 1e-3 * (1 + fr.v_color[..., 3].sum())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("width,height", SIZES)
 def test_atrous_each_iteration(rmd, orc, cuda, width, height, variant):
     """Every iteration in isolation (oracle-fed input): direct kernel (1), LDS stream kernel with
@@ -134,7 +134,7 @@ def test_stream_kernel_equals_direct_kernel_bitwise(rmd, cuda, width, height):
     src = c
     for it in range(5):
         outs = []
-        for variant in (1, 2, 3, 5, 4, 6, 0, 7):
+        for variant in (1, 2, 3, 5, 4, 6, 0, 7, 8):
             p.atrous_variant = variant
             o = torch.full_like(c, float("nan"))
             rmd.svgf.atrous(d, p, it, src, o, 0, height)
@@ -144,6 +144,7 @@ def test_stream_kernel_equals_direct_kernel_bitwise(rmd, cuda, width, height):
             assert torch.equal(outs[0], outs[k]), f"iteration {it} variant {name}: {(outs[0] != outs[k]).sum().item()} values differ"
         assert torch.equal(outs[3], outs[4]), f"iteration {it} pair kernel vs its direct form: {(outs[3] != outs[4]).sum().item()} values differ"
         assert torch.equal(outs[3], outs[7]), f"iteration {it} loader/consumer kernel vs the direct form: {(outs[3] != outs[7]).sum().item()} values differ"
+        assert torch.equal(outs[3], outs[8]), f"iteration {it} 2x2-block kernel vs the direct form: {(outs[3] != outs[8]).sum().item()} values differ"
         src = outs[2]
     # the counter protocol of variant 7 never ran into one of its bounded waits
     import ctypes
@@ -160,7 +161,7 @@ def test_atrous_zero_normals_cornell(rmd, orc, cuda):
     fr = orc.Frame(w, h, color, nd, motion)
     p = orc.default_params()
     d, t, _ = gpu_frame_desc(rmd, fr)
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):
         p.atrous_variant = variant
         src = color
         for it in range(5):
@@ -248,7 +249,7 @@ def test_zero_variance_settings_are_fenced(rmd, orc, cuda, over):
         assert (err <= TOL_FRAME).mean() >= 0.999, f"frame {f} {over}: {(err > TOL_FRAME).sum()} of {err.size} values beyond {TOL_FRAME}"
 
 
-@pytest.mark.parametrize("variant", [1, 3, 4, 5, 7])
+@pytest.mark.parametrize("variant", [1, 3, 4, 5, 7, 8])
 def test_saturated_colours_keep_blue_non_negative(rmd, orc, cuda, variant):
     """The kernels carry blue as luminance and recover it as (L - .2126 R - .7152 G) / .0722, which
     amplifies the rounding of L 14 times: with B = 0 and large R, G the recovered value must be clamped at
@@ -528,7 +529,7 @@ def test_degenerate_frame_sizes(rmd, orc, cuda, width, height):
         torch.cuda.synchronize()
         assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}"
         close(out, fr.out_color, TOL_FRAME, f"{width}x{height} frame {f}")
-    for variant in (0, 1, 2, 3, 4, 5, 6, 7):                # every a-trous variant on the last frame's input
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7, 8):             # every a-trous variant on the last frame's input
         p.atrous_variant = variant
         d, t, _ = gpu_frame_desc(rmd, ref[-1])
         src = ref[-1].v_color
