@@ -391,7 +391,8 @@ def main():
     # With N > 1 the second stream is on by default: it carries the RCCL history halo exchange, which
     # then runs underneath the a-trous iterations instead of in front of the next frame.
     pipelined = os.environ.get("RMD_PIPELINE", "1" if world > 1 else "0") == "1"
-    sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world, pipelined=pipelined)
+    reserve = int(os.environ.get("RMD_RESERVE_PER_XCD", "0")) if pipelined else 0
+    sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world, pipelined=pipelined, reserve_per_xcd=reserve)
     plan = sd.plan
     rows_out = plan.row1 - plan.row0
 

@@ -146,7 +146,8 @@ typedef struct rmd_svgf_params {
     int   tv_workgroups;    /* 0   T and V as one workgroup per 64x4 tile (default, fastest) | N > 0: N persistent
                                    workgroups that walk the tiles: a constant register footprint beside another
                                    frame's a-trous launches (experimental, slower so far); same results either way */
-    int   reserved1;
+    int   atrous_cus;       /* 0   CUs the a-trous launches may count on when they size their bands (0 = all CUs of
+                                   the device; set it to the CU count of a partition stream, rmd_stream_create_partition) */
 } rmd_svgf_params;
 
 void rmd_svgf_default_params(rmd_svgf_params* p);
@@ -315,6 +316,11 @@ int  rmd_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream
 int  rmd_host_alloc_pinned(void** ptr, size_t bytes);
 int  rmd_host_free_pinned(void* ptr);
 int  rmd_stream_create(void** stream);
+/* A stream restricted to a share of the CUs (hipExtStreamCreateWithCUMask): `reserve_per_xcd` (4, 8 ... 28) CUs of
+ * every XCD are set aside; side 1 runs on those only, side 0 on all the others.  *cus_out = CUs the stream may use.
+ * For frame pipelining: the HBM-bound T + V of frame k+1 on a few CUs beside the ALU-bound a-trous launches of
+ * frame k on the rest (pass that CU count as rmd_svgf_params.atrous_cus). */
+int  rmd_stream_create_partition(void** stream, int reserve_per_xcd, int side, int* cus_out);
 int  rmd_stream_destroy(void* stream);
 int  rmd_stream_sync(void* stream);
 /* events order work across streams (frame pipelining): record on one stream, wait on another */

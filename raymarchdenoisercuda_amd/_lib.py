@@ -55,7 +55,7 @@ class SvgfParams(C.Structure):
                 ("var_h_threshold", C.c_int), ("var_radius", C.c_int),
                 ("sigma_n", C.c_float), ("sigma_z", C.c_float), ("sigma_l", C.c_float),
                 ("iterations", C.c_int), ("hist_iteration", C.c_int), ("atrous_variant", C.c_int),
-                ("tv_workgroups", C.c_int), ("reserved1", C.c_int)]
+                ("tv_workgroups", C.c_int), ("atrous_cus", C.c_int)]
 
 
 class SvgfFrameDesc(C.Structure):
@@ -132,6 +132,7 @@ SYMBOLS = {
     "rmd_host_alloc_pinned": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "rmd_host_free_pinned": (C.c_int, [_P]),
     "rmd_stream_create": (C.c_int, [C.POINTER(_P)]),
+    "rmd_stream_create_partition": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rmd_stream_destroy": (C.c_int, [_P]),
     "rmd_stream_sync": (C.c_int, [_P]),
     "rmd_event_create": (C.c_int, [C.POINTER(_P)]),

@@ -64,6 +64,7 @@ struct AtrousArgs {
     // pair kernel: strips that touch the left / right frame border run the slower per-lane-tested body and get
     // bands of half the height (xe_lo of them at the left, the rest of the non-interior ones at the right)
     int n_int, xe_lo, band_h_xe, total_int, int_per_xcd, xe_per_xcd;
+    int cus;       // CUs the launch may count on (rmd_svgf_params.atrous_cus or the whole device)
     int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
 };
 
@@ -2216,7 +2217,7 @@ static int launch_pair(AtrousArgs a, hipStream_t stream)
     // fills the rounds best, discounted by the 4 halo rows a workgroup stages on top of its own rows.
     // (3840 wide: 28 interior + 2 border strips = 32 S b workgroups, i.e. exactly 768 for S <= 8.)
     const int unit = S * (LC ? LcCfg<S>::NC : QD ? QuadCfg<S>::ADV : C::ADV);
-    const int slots = (LC ? LcCfg<S>::WG_PER_CU : QD ? QuadCfg<S>::WG_PER_CU : C::WG_PER_CU) * device_cus();
+    const int slots = (LC ? LcCfg<S>::WG_PER_CU : QD ? QuadCfg<S>::WG_PER_CU : C::WG_PER_CU) * a.cus;
     int best_nb = 1;
     double best = -1.0;
     for (int nb = 1; nb <= 64; ++nb) {
@@ -2301,7 +2302,7 @@ static double plan_stream(AtrousArgs& a)
     // Number of bands: every workgroup does the same work, so the launch runs in
     // ceil(workgroups / resident slots) rounds; pick the band count that fills the rounds best,
     // discounted by the 4 halo rows each workgroup stages on top of its own lattice rows.
-    const int slots = C::WG_PER_CU * device_cus();
+    const int slots = C::WG_PER_CU * a.cus;
     static const int min_rounds = [] { const char* e = getenv("RMD_ATROUS_MIN_ROUNDS"); return e ? atoi(e) : 1; }();
     int bh = ((rows + unit - 1) / unit) * unit;
     double best = -1.0;
@@ -2417,6 +2418,8 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     a.band_h = a.band_base = a.nstrips = a.nblocks = a.per_xcd = 0;
     a.n_int = a.xe_lo = a.band_h_xe = a.total_int = a.int_per_xcd = a.xe_per_xcd = 0;
     a.nt_out = (double)(row1 - row0) * f->width * 48.0 > 256.0e6 ? 1 : 0;
+    if (p->atrous_cus < 0) return fail(RMD_E_PARAM, "rmd_svgf_atrous: atrous_cus %d is negative", p->atrous_cus);
+    a.cus = p->atrous_cus > 0 && p->atrous_cus < device_cus() ? p->atrous_cus : device_cus();
 
     int variant = p->atrous_variant;
     if (variant == 0) {

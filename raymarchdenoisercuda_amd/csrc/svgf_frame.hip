@@ -66,7 +66,7 @@ void rmd_svgf_default_params(rmd_svgf_params* p)
     p->var_h_threshold = 4; p->var_radius = 3;
     p->sigma_n = 128.0f; p->sigma_z = 1.0f; p->sigma_l = 4.0f;
     p->iterations = 5; p->hist_iteration = 0; p->atrous_variant = 0;
-    p->tv_workgroups = 0; p->reserved1 = 0;
+    p->tv_workgroups = 0; p->atrous_cus = 0;
 }
 
 int rmd_svgf_frame_reach(const rmd_svgf_params* p, int reach[4])

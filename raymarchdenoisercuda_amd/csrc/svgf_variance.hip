@@ -9,6 +9,7 @@
 // re-reads are served by L1/L2.  Frame statistics (sum of variance, spatial-path pixel count,
 // sum of history length, pixel count) are reduced across the wavefront with __shfl_xor
 // butterflies and committed with one atomic per wave.
+#include <cstdlib>
 #include "common.h"
 
 namespace rmd {
@@ -193,8 +194,10 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z;
     dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
     if (p->tv_workgroups < 0 || p->tv_workgroups > 65536) return fail(RMD_E_PARAM, "rmd_svgf_variance: tv_workgroups %d outside [0,65536]", p->tv_workgroups);
-    if (a.tile_flags && p->tv_workgroups > 0) {
-        const dim3 pg(p->tv_workgroups);
+    static const int env_wgs = [] { const char* e = getenv("RMD_V_WORKGROUPS"); return e ? atoi(e) : -1; }();
+    const int v_wgs = p->tv_workgroups > 0 ? p->tv_workgroups : env_wgs;
+    if (a.tile_flags && v_wgs > 0) {
+        const dim3 pg(v_wgs);
         if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_persistent_kernel<3>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
         else               hipLaunchKernelGGL(svgf_variance_persistent_kernel<0>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
     } else {
