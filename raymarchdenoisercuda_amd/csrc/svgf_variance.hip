@@ -139,6 +139,120 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
     }
 }
 
+// Fused frames (tile flags from T, v_color prefilled, no statistics), radius 3.  In the steady state ~2 % of the
+// tiles are flagged (disocclusion bands), and the launch had two costs of ~40 us each at 4K, whichever form it
+// took: one workgroup per tile is bound by launching and retiring 130 k waves that only read a flag; a few
+// thousand workgroups walking the flags are bound by the flagged tile itself, a chain of 7 x 14 dependent
+// gathers per pixel.  This kernel removes both: kVGrid workgroups (a prime, so the tiles of a vertical or a
+// horizontal band land on different workgroups) each test every kVGrid-th flag with one load + ballot, and a
+// flagged tile first stages its 70 x 10 neighbourhood of t_color and nd in LDS with six coalesced loads per
+// thread, all in flight together; the 49 taps read LDS.  Same taps, order and arithmetic as variance_pixel:
+// identical bits.  4K steady state (~750 flagged tiles, ~10 k short-history pixels): 38 -> 26 us, of which 4.5 are
+// the empty launch, 2.4 the staging and the rest the tap bodies on the CUs that hold several flagged tiles;
+// a frame after a scene cut (every tile flagged): 670 -> 590 us.
+constexpr int kVR = 3, kVW = 64 + 2 * kVR, kVH = 4 + 2 * kVR;      // staged region 70 x 10
+constexpr int kVGrid = 2039;
+__global__ __launch_bounds__(256) void svgf_variance_tile_kernel(VarianceArgs a, int tiles_y)
+{
+    __shared__ float4 sc[kVH][kVW], sn[kVH][kVW];
+    __shared__ int todo[256], wave_count[4];
+    const Geom g = a.g;
+    const int ntiles = a.tiles_x * tiles_y;
+    const int lane = threadIdx.x & 63;
+    const unsigned char* flags = a.tile_flags + (size_t)(a.row0 / 4) * a.tiles_x;
+    // rows that exist in this buffer: the launcher checked that [row0 - 3, row1 + 3) clamped to the frame is inside
+    const int blo = max(g.buf_row0, 0), bhi = min(g.buf_row0 + g.buf_rows, g.H);
+    for (int base = 0; base < ntiles; base += 64 * (int)gridDim.x) {
+        const int t = base + lane * (int)gridDim.x + (int)blockIdx.x;
+        unsigned long long m = __builtin_amdgcn_ballot_w64(t < ntiles && flags[t] != 0);    // the same in all four waves
+        while (m) {
+            const int k = __builtin_ctzll(m);
+            m &= m - 1;
+            const int tile = base + k * (int)gridDim.x + (int)blockIdx.x;
+            const int x0 = (tile % a.tiles_x) * 64, y0 = (a.row0 / 4 + tile / a.tiles_x) * 4;
+            for (int q = threadIdx.x; q < kVW * kVH; q += 256) {
+                const int ry = q / kVW, rx = q - ry * kVW;
+                const int tx = min(max(x0 - kVR + rx, 0), g.W - 1), ty = min(max(y0 - kVR + ry, blo), bhi - 1);
+                const size_t ti = pix_index(g, tx, ty);
+                sc[ry][rx] = a.t_color[ti];
+                sn[ry][rx] = a.nd[ti];
+            }
+            // The short-history pixels of a flagged tile are few (a band a few pixels wide: ~13 of 256 in the steady
+            // state), and a wave with one such lane pays for the whole 49-tap body: compact them to the first
+            // threads of the workgroup, so that one wave does the work of four.
+            int h = 0;
+            {
+                const int x = x0 + (threadIdx.x & 63), y = y0 + (threadIdx.x >> 6);
+                const bool active = x < g.W && y >= a.row0 && y < a.row1;
+                if (active) h = (int)a.t_moments[pix_index(g, x, y)].z;
+                const bool spatial = active && h < a.h_threshold;  // (else v_color already holds t_color)
+                const unsigned long long b = __builtin_amdgcn_ballot_w64(spatial);
+                const int wave = threadIdx.x >> 6;
+                if (lane == 0) wave_count[wave] = __builtin_popcountll(b);
+                __syncthreads();                                   // also: the staged region is complete
+                int pos = __builtin_popcountll(b & ((1ull << lane) - 1ull));
+                for (int w = 0; w < wave; ++w) pos += wave_count[w];
+                if (spatial) todo[pos] = (int)threadIdx.x | (h << 8);
+                __syncthreads();
+            }
+            const int ntodo = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+            if ((int)threadIdx.x < ntodo) {
+                const int id = todo[threadIdx.x];
+                const int lx = id & 63, ly = (id >> 6) & 3;
+                h = id >> 8;
+                const int x = x0 + lx, y = y0 + ly;
+                const float4 c = sc[ly + kVR][lx + kVR];
+                const float4 nd = sn[ly + kVR][lx + kVR];
+                const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
+                const float gz = fabsf(sn[ly + kVR][x1 - x0 + kVR].w - nd.w) + fabsf(sn[y1 - y0 + kVR][lx + kVR].w - nd.w);
+                const float za = a.sigma_z * fmaxf(gz, 1e-8f);
+                const bool p_zero = is_zero3(nd);
+                float sw = 0.0f, scx = 0.0f, scy = 0.0f, scz = 0.0f, sl = 0.0f, sl2 = 0.0f;
+                // both loops unrolled: tap lengths become constants (nine distinct reciprocals instead of 48 square
+                // roots and divisions) and the LDS reads of neighbouring taps overlap -- the few lanes that get
+                // here are a latency chain, not a throughput problem
+#pragma unroll
+                for (int dx = -kVR; dx <= kVR; ++dx) {
+#pragma unroll
+                    for (int dy = -kVR; dy <= kVR; ++dy) {
+                        const int tx = x + dx, ty = y + dy;
+                        if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
+                        const float4 tc = sc[ly + kVR + dy][lx + kVR + dx];
+                        const float4 tn = sn[ly + kVR + dy][lx + kVR + dx];
+                        float e;
+                        const bool t_zero = is_zero3(tn);
+                        if (p_zero || t_zero) {
+                            e = (p_zero && t_zero) ? 0.0f : kNegInf;
+                        } else {
+                            const float d = __builtin_fmaf(nd.z, tn.z, __builtin_fmaf(nd.y, tn.y, nd.x * tn.x));
+                            e = a.sigma_n * fast_log2(fmaxf(d, 0.0f));
+                        }
+                        if (dx != 0 || dy != 0) {
+                            const float len = sqrtf((float)(dx * dx + dy * dy));
+                            e = __builtin_fmaf(-fabsf(nd.w - tn.w), kLog2e / (za * len + 1e-8f), e);
+                        }
+                        const float w = fast_exp2(e);
+                        const float tl = lum3(tc.x, tc.y, tc.z);
+                        sw += w;
+                        scx = __builtin_fmaf(w, tc.x, scx); scy = __builtin_fmaf(w, tc.y, scy); scz = __builtin_fmaf(w, tc.z, scz);
+                        sl = __builtin_fmaf(w, tl, sl); sl2 = __builtin_fmaf(w, tl * tl, sl2);
+                    }
+                }
+                float4 o = c;
+                if (!(sw < 1e-10f)) {
+                    const float el = sl / sw, el2 = sl2 / sw;
+                    float var = el2 - el * el;
+                    if (!(var > 0.0f)) var = 0.0f;
+                    var *= 4.0f / (float)max(h, 1);
+                    o = make_float4(scx / sw, scy / sw, scz / sw, var);
+                }
+                a.v_color[pix_index(g, x, y)] = o;
+            }
+            __syncthreads();                                       // the next flagged tile restages the LDS region
+        }
+    }
+}
+
 // Fused frames only (tile flags from T, no statistics): a fixed number of workgroups, each looking
 // at the flags of every gridDim.x-th tile (64 per coalesced-by-stride load and ballot) and running
 // the flagged ones.  Constant footprint, for the same reason as svgf_temporal_persistent_kernel; the
@@ -200,6 +314,8 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
         const dim3 pg(v_wgs);
         if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_persistent_kernel<3>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
         else               hipLaunchKernelGGL(svgf_variance_persistent_kernel<0>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
+    } else if (a.tile_flags && a.radius == kVR && v_wgs != 0) {
+        hipLaunchKernelGGL(svgf_variance_tile_kernel, dim3(kVGrid), dim3(256), 0, as_stream(stream), a, (int)grid.y);
     } else {
         if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_kernel<3>, grid, dim3(256), 0, as_stream(stream), a);
         else               hipLaunchKernelGGL(svgf_variance_kernel<0>, grid, dim3(256), 0, as_stream(stream), a);
