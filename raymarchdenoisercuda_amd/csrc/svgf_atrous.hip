@@ -64,6 +64,7 @@ struct AtrousArgs {
     // pair kernel: strips that touch the left / right frame border run the slower per-lane-tested body and get
     // bands of half the height (xe_lo of them at the left, the rest of the non-interior ones at the right)
     int n_int, xe_lo, band_h_xe, total_int, int_per_xcd, xe_per_xcd;
+    int n_hi, band_h_hi, nblocks_hi;   // stream kernel: the first n_hi/2 and last n_hi - n_hi/2 strips are cut into bands of band_h_hi (< band_h) rows
     int cus;       // CUs the launch may count on (rmd_svgf_params.atrous_cus or the whole device)
     int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
 };
@@ -751,13 +752,22 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(A
     const int pid = blockIdx.x;
     const int L = (pid & (kXcds - 1)) * a.per_xcd + (pid >> 3);
     if (L >= a.nblocks) return;
-    const int r = L % S, t = L / S;
-    const int strip = t % a.nstrips, band = t / a.nstrips;
+    // Two groups of strips: n_hi strips (the outermost ones: their frame-edge body is the slower one) are cut into
+    // one band more than the others, so that the workgroup count lands on the resident slots (plan_stream).
+    int strip, band, bh;
+    const int r = L % S;
+    if (L < a.nblocks_hi) {
+        const int t = L / S, e = t % a.n_hi;
+        strip = e < a.n_hi / 2 ? e : a.nstrips - (a.n_hi - e); band = t / a.n_hi; bh = a.band_h_hi;
+    } else {
+        const int t = (L - a.nblocks_hi) / S, n_lo = a.nstrips - a.n_hi;
+        strip = a.n_hi / 2 + t % n_lo; band = t / n_lo; bh = a.band_h;
+    }
     const int x0 = strip * C::CW;
-    // bands start at band_base + k*band_h; band_base is row0 rounded down to a multiple of 2S, which is
+    // bands start at band_base + k*bh; band_base is row0 rounded down to a multiple of 2S, which is
     // all the (A,B) pairing needs (global lattice index floor(y/S) even at the top of a band)
-    const int yb = a.band_base + band * a.band_h;
-    const int lo = max(yb, a.row0), hi = min(yb + a.band_h, a.row1);
+    const int yb = a.band_base + band * bh;
+    const int lo = max(yb, a.row0), hi = min(yb + bh, a.row1);
     const int ybase = yb + r;
     const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
     const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;      // exclusive
@@ -2303,24 +2313,43 @@ static double plan_stream(AtrousArgs& a)
     // ceil(workgroups / resident slots) rounds; pick the band count that fills the rounds best,
     // discounted by the 4 halo rows each workgroup stages on top of its own lattice rows.
     const int slots = C::WG_PER_CU * a.cus;
-    static const int min_rounds = [] { const char* e = getenv("RMD_ATROUS_MIN_ROUNDS"); return e ? atoi(e) : 1; }();
-    int bh = ((rows + unit - 1) / unit) * unit;
+    // Candidates: nb bands for every strip, or nb + 1 for x of the strips, x as large as the rounds nb needs
+    // anyway leave room for (3840 wide, step 2: 30 strips x 2 lattices x 12 bands = 720 workgroups for 768 slots
+    // left 48 CUs with two workgroups instead of three; 24 strips with 13 bands make it 768).
+    static const int mixed = [] { const char* e = getenv("RMD_ATROUS_MIXED_BANDS"); return e ? atoi(e) : 1; }();
+    auto round_up = [&](int h) { return ((h + unit - 1) / unit) * unit; };
+    int best_h = round_up(rows), best_hh = best_h, best_x = 0;
     double best = -1.0;
     for (int nb = 1; nb <= 64; ++nb) {
-        int h = (rows + nb - 1) / nb;
-        h = ((h + unit - 1) / unit) * unit;
+        const int h = round_up((rows + nb - 1) / nb);
         const int bands = (rows + h - 1) / h;
-        const int wgs = bands * per_band;
-        const int rounds = (wgs + slots - 1) / slots;
-        const double lattice_rows = (double)h / S;
-        const double eff = (double)wgs / ((double)rounds * slots) * lattice_rows / (lattice_rows + 4.0);
-        if (rounds < min_rounds && h > unit) continue;
-        if (eff > best + 1e-9) { best = eff; bh = h; }
+        const int wgs0 = bands * per_band;
+        const int rounds = (wgs0 + slots - 1) / slots;
+        int hh = h, x = 0;
+        if (mixed && h > unit && rounds == 1) {          // (with two or more rounds the late workgroups backfill anyway)
+            const int h2 = round_up((rows + bands) / (bands + 1));
+            const int bands2 = (rows + h2 - 1) / h2;
+            // only where the two sizes stay close (>= 6 bands): a CU runs whichever three workgroups it is
+            // dealt, and 4 against 3 bands (let alone 2 against 1) leaves the CUs with the big ones behind
+            if (h2 < h && bands2 > bands && h2 * 100 >= h * 85) {
+                x = min(a.nstrips, (rounds * slots - wgs0) / (S * (bands2 - bands)));
+                if (x > 0) hh = h2;
+            }
+        }
+        const int bands_hi = (rows + hh - 1) / hh;
+        const int wgs = wgs0 + x * S * (bands_hi - bands);
+        // staged lattice rows of the launch over what its rounds could hold; a CU's time is the sum of its workgroups
+        const double avg_rows = ((double)(a.nstrips - x) * bands * h + (double)x * bands_hi * hh) / ((double)(a.nstrips - x) * bands + (double)x * bands_hi) / S;
+        const double eff = (double)wgs / ((double)rounds * slots) * avg_rows / (avg_rows + 4.0);
+        if (eff > best + 1e-9) { best = eff; best_h = h; best_hh = hh; best_x = x; }
         if (h == unit) break;
     }
-    a.band_h = bh;
-    const int nbands = (rows + bh - 1) / bh;
-    a.nblocks = nbands * per_band;
+    a.band_h = best_h;
+    a.band_h_hi = best_hh;
+    a.n_hi = best_x;
+    const int nbands = (rows + best_h - 1) / best_h, nbands_hi = (rows + best_hh - 1) / best_hh;
+    a.nblocks_hi = best_x * S * nbands_hi;
+    a.nblocks = a.nblocks_hi + (a.nstrips - best_x) * S * nbands;
     a.per_xcd = (a.nblocks + kXcds - 1) / kXcds;
     return best;
 }
@@ -2417,6 +2446,7 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z; a.sigma_l = p->sigma_l;
     a.band_h = a.band_base = a.nstrips = a.nblocks = a.per_xcd = 0;
     a.n_int = a.xe_lo = a.band_h_xe = a.total_int = a.int_per_xcd = a.xe_per_xcd = 0;
+    a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
     a.nt_out = (double)(row1 - row0) * f->width * 48.0 > 256.0e6 ? 1 : 0;
     if (p->atrous_cus < 0) return fail(RMD_E_PARAM, "rmd_svgf_atrous: atrous_cus %d is negative", p->atrous_cus);
     a.cus = p->atrous_cus > 0 && p->atrous_cus < device_cus() ? p->atrous_cus : device_cus();
