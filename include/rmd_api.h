@@ -169,7 +169,9 @@ typedef struct rmd_svgf_frame_desc {
     const float* hist_moments; /* float4 (m1, m2, history length, 0)                            */
     const float* prev_nd;      /* float4                                                        */
     /* intermediates / outputs */
-    float* t_color;            /* T out: float4 (c', variance)                                  */
+    float* t_color;            /* T out: float4 (c', variance).  rmd_svgf_frame / rmd_svgf_frame_tv with v_tile_flags set
+                                  treat it as scratch: only the 64x4 tiles T flags for V are written (v_color holds
+                                  T's output for every pixel); rmd_svgf_temporal always writes all of it            */
     float* t_moments;          /* T out: float4 (m1', m2', h, 0) -> next frame's hist_moments   */
     int*   t_debug;            /* optional int4 (q0.x, q0.y, tap mask, h): the bit-exact outputs */
     float* v_color;            /* V out: float4                                                 */

@@ -63,6 +63,8 @@ int check_rows_in_buffer(const rmd_svgf_frame_desc* f, int lo, int hi, const cha
 int run_weighted_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStream_t stream);
 int launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
 int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
+// fused frame whose V pass is svgf_variance_tile_kernel: T then writes t_color only inside the tiles it flags
+bool variance_reads_sparse_t_color(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, bool fused);
 
 }  // namespace rmd
 

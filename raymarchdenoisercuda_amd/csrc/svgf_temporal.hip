@@ -22,6 +22,8 @@ struct TemporalArgs {
     float4* v_color;          // optional second copy of t_color (fused frame: V then only rewrites short-history pixels)
     unsigned char* tile_flags; // optional: 1 per 64x4 tile (global tiling) holding a pixel with h < var_h_threshold
     int tiles_x, var_h_threshold;
+    int sparse_t_color;        // fused frame with the tile form of V: t_color is written only inside flagged tiles (V reads
+                               // every other pixel of its windows from v_color, which holds the same values there)
     int row0, row1;
     float alpha_color, alpha_moments, k_z, k_n;
     int h_max, max_motion_rows;
@@ -36,8 +38,11 @@ __device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int t
     const int x = tile_x * 64 + (threadIdx.x & 63);
     const int y = tile_y * 4 + (threadIdx.x >> 6);
     bool short_history = false;
-    if (x < g.W && y >= a.row0 && y < a.row1) {
-    const size_t i = pix_index(g, x, y);
+    const bool active = x < g.W && y >= a.row0 && y < a.row1;
+    float4 tc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    size_t i = 0;
+    if (active) {
+    i = pix_index(g, x, y);
 
     const float4 c = a.color[i];
     const float4 nd = a.nd[i];
@@ -124,8 +129,8 @@ __device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int t
     float var = m2 - m1 * m1;
     if (!(var > 0.0f)) var = 0.0f;
 
-    const float4 tc = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
-    a.t_color[i] = tc;
+    tc = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
+    if (!a.sparse_t_color) a.t_color[i] = tc;
     if (a.v_color) a.v_color[i] = tc;
     a.t_moments[i] = make_float4(m1, m2, (float)h, 0.0f);
     if (a.t_debug) a.t_debug[i] = make_int4(q0x, q0y, mask, h);
@@ -134,6 +139,8 @@ __device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int t
     if (a.tile_flags) {
         const int any = __syncthreads_or(short_history ? 1 : 0);
         if (threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + tile_x] = (unsigned char)(any != 0);
+        // 16 of T's 136 B per pixel: in the steady state ~2 % of the tiles are flagged
+        if (a.sparse_t_color && any && active) a.t_color[i] = tc;
     }
 }
 
@@ -195,6 +202,7 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.prev_nd = (const float4*)f->prev_nd;
     a.t_color = (float4*)f->t_color; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
     a.v_color = nullptr;
+    a.sparse_t_color = rmd::variance_reads_sparse_t_color(f, p, fused) ? 1 : 0;
     a.tile_flags = nullptr; a.tiles_x = (f->width + 63) / 64; a.var_h_threshold = p->var_h_threshold;
     if (fused) {
         a.tile_flags = f->v_tile_flags;

@@ -23,6 +23,7 @@ struct VarianceArgs {
     int prefilled;            // v_color already holds t_color (fused frame): long-history pixels are left alone
     const unsigned char* tile_flags;   // fused frame: tiles T marked as holding short-history pixels
     int tiles_x;
+    int sparse_t_color;       // T wrote t_color only inside flagged tiles: elsewhere v_color holds the same values
     float sigma_n, sigma_z;
 };
 
@@ -174,7 +175,11 @@ __global__ __launch_bounds__(256) void svgf_variance_tile_kernel(VarianceArgs a,
                 const int ry = q / kVW, rx = q - ry * kVW;
                 const int tx = min(max(x0 - kVR + rx, 0), g.W - 1), ty = min(max(y0 - kVR + ry, blo), bhi - 1);
                 const size_t ti = pix_index(g, tx, ty);
-                sc[ry][rx] = a.t_color[ti];
+                // a pixel of a tile T did not flag was not written to t_color (sparse_t_color); V never writes such
+                // a pixel either, so v_color still holds T's value for it
+                const float4* src = a.t_color;
+                if (a.sparse_t_color && a.tile_flags[(size_t)(ty >> 2) * a.tiles_x + (tx >> 6)] == 0) src = a.v_color;
+                sc[ry][rx] = src[ti];
                 sn[ry][rx] = a.nd[ti];
             }
             // The short-history pixels of a flagged tile are few (a band a few pixels wide: ~13 of 256 in the steady
@@ -281,6 +286,18 @@ __global__ __launch_bounds__(256) void svgf_variance_persistent_kernel(VarianceA
 
 using namespace rmd;
 
+static int env_v_workgroups()
+{
+    static const int v = [] { const char* e = getenv("RMD_V_WORKGROUPS"); return e ? atoi(e) : -1; }();
+    return v;
+}
+
+bool rmd::variance_reads_sparse_t_color(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, bool fused)
+{
+    static const int sparse = [] { const char* e = getenv("RMD_SPARSE_T_COLOR"); return e ? atoi(e) : 1; }();
+    return sparse && fused && !f->stats && f->v_tile_flags && p->var_radius == kVR && p->tv_workgroups == 0 && env_v_workgroups() < 0;
+}
+
 int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused)
 {
     if (int e = check_frame_geometry(f)) return e;
@@ -308,8 +325,8 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.sigma_n = p->sigma_n; a.sigma_z = p->sigma_z;
     dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
     if (p->tv_workgroups < 0 || p->tv_workgroups > 65536) return fail(RMD_E_PARAM, "rmd_svgf_variance: tv_workgroups %d outside [0,65536]", p->tv_workgroups);
-    static const int env_wgs = [] { const char* e = getenv("RMD_V_WORKGROUPS"); return e ? atoi(e) : -1; }();
-    const int v_wgs = p->tv_workgroups > 0 ? p->tv_workgroups : env_wgs;
+    const int v_wgs = p->tv_workgroups > 0 ? p->tv_workgroups : env_v_workgroups();
+    a.sparse_t_color = variance_reads_sparse_t_color(f, p, fused) ? 1 : 0;
     if (a.tile_flags && v_wgs > 0) {
         const dim3 pg(v_wgs);
         if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_persistent_kernel<3>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
