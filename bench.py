@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 ATROUS_BYTES_PER_PX = 48       # per iteration: color 16 + nd 16 read, color 16 written
 FULL_BYTES_PER_PX = 424        # T 120 + V 64 + 5 x 48, every pass priced on its own
-MOVED_BYTES_PER_PX = 376       # what rmd_svgf_frame moves: T 120 + 16 (it also writes v_color), V ~0 (flagged tiles only), 5 x 48
+MOVED_BYTES_PER_PX = 360       # what rmd_svgf_frame moves: T 88 read + 32 written (v_color, t_moments; t_color only in the
+                               # ~2 % of tiles it flags for V), V ~0 (flagged tiles only), 5 x 48
 MAX_RESIDENT = 64              # pre-generated G-buffer frames kept in HBM
 
 
@@ -440,7 +441,7 @@ def main():
                    "parallelism": f"row-strip x{world}", "passes": "T + V + 5 x A (7 launches/frame)",
                    "frame_pipelining": "T+V of frame k+1 overlap A1..A4 of frame k (2 streams)" if pipelined else "none"},
         # 424 B/px is SURVEY §8(d)'s per-pass algorithmic count; with V's pass-through copy fused into T the
-        # frame actually moves 376 B/px, which is the figure to hold against the HBM peak
+        # frame actually moves 360 B/px, which is the figure to hold against the HBM peak
         "effective_GBps_full_svgf": round(FULL_BYTES_PER_PX * total_px / dt / 1e9, 1),
         "moved_GBps_full_svgf": round(MOVED_BYTES_PER_PX * total_px / dt / 1e9, 1),
         "bytes_per_px": {"algorithmic_per_pass_sum": FULL_BYTES_PER_PX, "moved_with_V_fused_into_T": MOVED_BYTES_PER_PX},
