@@ -198,6 +198,12 @@ int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int 
 /* Variant 7 synchronises its waves with counters in LDS; every wait is bounded, and a wait that runs out
  * is counted here instead of hanging the GPU (synchronises the device; 0 after any number of correct launches). */
 int rmd_debug_atrous_protocol_errors(unsigned int* count);
+/* The work decomposition the default a-trous kernel (128-column strips) would use for rows [row0,row1) of a
+ * width x height frame on `cus` CUs; host arithmetic only, no device needed.  out[8] = workgroups, strips, first band
+ * row, band height, band height of the strips that get one band more, number of those strips (the outermost: the first
+ * n/2 and the last n - n/2), workgroups of those strips (they come first in the order), workgroup slots per XCD.
+ * Workgroup L (< out[0]): lattice L % step; strip group and band as in atrous_stream_kernel.  For tests.          */
+int rmd_debug_atrous_plan(int width, int height, int row0, int row1, int iteration, int cus, int* out);
 /* T + V + `iterations` x A for final output rows [row0,row1).  Earlier passes are computed on
  * the rows later passes tap (redundant rows instead of per-pass halo exchanges);
  * those rows are clamped to the global frame and must lie inside the buffer. */

@@ -2416,6 +2416,28 @@ static int launch_stream_auto_iter(int iteration, const AtrousArgs& a, hipStream
 
 using namespace rmd;
 
+extern "C" int rmd_debug_atrous_plan(int width, int height, int row0, int row1, int iteration, int cus, int* out)
+{
+    if (!out) return fail(RMD_E_NULL, "rmd_debug_atrous_plan: out is NULL");
+    if (width < 1 || height < 1 || row0 < 0 || row1 > height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_debug_atrous_plan: frame %dx%d rows [%d,%d) invalid", width, height, row0, row1);
+    if (iteration < 0 || iteration > 4) return fail(RMD_E_PARAM, "rmd_debug_atrous_plan: iteration %d outside [0,4]", iteration);
+    if (cus < 1) return fail(RMD_E_PARAM, "rmd_debug_atrous_plan: cus %d", cus);
+    AtrousArgs a;
+    a.g = Geom{ width, height, 0, height };
+    a.row0 = row0; a.row1 = row1; a.step = 1 << iteration; a.cus = cus;
+    a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
+    switch (iteration) {
+        case 0: plan_stream<1, 2>(a); break;
+        case 1: plan_stream<2, 2>(a); break;
+        case 2: plan_stream<4, 2>(a); break;
+        case 3: plan_stream<8, 2>(a); break;
+        default: plan_stream<16, 2>(a); break;
+    }
+    out[0] = a.nblocks; out[1] = a.nstrips; out[2] = a.band_base; out[3] = a.band_h; out[4] = a.band_h_hi;
+    out[5] = a.n_hi; out[6] = a.nblocks_hi; out[7] = a.per_xcd;
+    return RMD_OK;
+}
+
 extern "C" int rmd_debug_atrous_protocol_errors(unsigned int* count)
 {
     if (!count) return fail(RMD_E_NULL, "rmd_debug_atrous_protocol_errors: count is NULL");
