@@ -2,6 +2,8 @@
 #   make lib      -> raymarchdenoisercuda_amd/lib/librmd.so
 #   make host     -> build/main  (the reference's `main -t [label]` CLI over the C ABI)
 #   make oracle   -> oracle/liboracle.so (test infrastructure only)
+#   make experiments -> build/variants/librmd_experiments.so: the same library + the kernels that were measured and lost
+#                    (-DRMD_EXPERIMENTS; select with RMD_LIB_PATH=...; their tests are marked `experiments`)
 HIPCC    ?= /opt/rocm/bin/hipcc
 CXX      ?= g++
 ARCH     ?= gfx950
@@ -23,7 +25,7 @@ all: lib oracle host
 
 lib: $(LIB)
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rmd_api.h Makefile
+build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rmd_api.h Makefile $(wildcard $(CSRC)/*.inc)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -40,8 +42,11 @@ build/main: $(HOSTSRC) $(LIB) $(wildcard include/*.h)
 	@mkdir -p build
 	$(CXX) $(HOSTFLAGS) -o $@ $(HOSTSRC) -L$(LIBDIR) -lrmd -lz -Wl,-rpath,'$$ORIGIN/../$(LIBDIR)'
 
+experiments:
+	tools/build_variant.sh experiments -DRMD_EXPERIMENTS
+
 clean:
 	rm -rf build $(LIB)
 	$(MAKE) -C oracle clean
 
-.PHONY: all lib oracle host clean
+.PHONY: all lib oracle host experiments clean

@@ -136,18 +136,18 @@ typedef struct rmd_svgf_params {
     float sigma_l;          /* 4   */
     int   iterations;       /* 5   step 2^i for i in [0, iterations)                           */
     int   hist_iteration;   /* 0   output of this iteration becomes next frame's hist_color    */
-    int   atrous_variant;   /* 0 auto (= 3 for iterations 0..4, 1 beyond) | row-pair formulation: 1 direct (taps from global memory, any step),
-                                   2 / 3 / 6 LDS row streaming with one / two / four row pairs per workgroup |
-                                   pixel-pair formulation: 4 LDS row streaming, 5 direct, 7 LDS row streaming with
-                                   loader waves feeding compute waves through counters instead of barriers, 8 LDS
-                                   row streaming with a 2x2 pixel block per lane (7 and 8 are measured experiments,
-                                   slower: DESIGN.md §4.6, §4.7).  0, 1, 2, 3, 6 give identical bits, so do 4, 5, 7
-                                   and 8 (the two families differ in the order of summation, i.e. by rounding)   */
-    int   tv_workgroups;    /* 0   T and V as one workgroup per 64x4 tile (default, fastest) | N > 0: N persistent
-                                   workgroups that walk the tiles: a constant register footprint beside another
-                                   frame's a-trous launches (experimental, slower so far); same results either way */
+    int   atrous_variant;   /* 0 auto (= 3 for iterations 0..4, 1 beyond) | 1 direct (taps from global memory, any
+                                   step; the cross-check) | 3 LDS row streaming, 128-column strips, two row pairs per
+                                   workgroup.  0, 1 and 3 give identical bits.  Experiments build only
+                                   (rmd_has_experiments(); RMD_E_UNSUPPORTED otherwise; measured slower, DESIGN.md
+                                   §4.4-4.7): 2 / 6 row streaming with one / four row pairs per workgroup (same bits);
+                                   pixel-pair formulation 4 LDS row streaming, 5 direct, 7 loader waves feeding
+                                   compute waves through counters, 8 a 2x2 pixel block per lane (4, 5, 7, 8 agree
+                                   with each other bit for bit and differ from 0/1/3 by rounding)              */
+    int   tv_workgroups;    /* 0   T and V as one workgroup per 64x4 tile | N > 0 (experiments build only): N
+                                   persistent workgroups that walk the tiles; same results, measured slower     */
     int   atrous_cus;       /* 0   CUs the a-trous launches may count on when they size their bands (0 = all CUs of
-                                   the device; set it to the CU count of a partition stream, rmd_stream_create_partition) */
+                                   the device; fewer when the caller knows other work holds part of the device)  */
 } rmd_svgf_params;
 
 void rmd_svgf_default_params(rmd_svgf_params* p);
@@ -324,11 +324,6 @@ int  rmd_memcpy_d2h_async(void* dst, const void* src, size_t bytes, void* stream
 int  rmd_host_alloc_pinned(void** ptr, size_t bytes);
 int  rmd_host_free_pinned(void* ptr);
 int  rmd_stream_create(void** stream);
-/* A stream restricted to a share of the CUs (hipExtStreamCreateWithCUMask): `reserve_per_xcd` (4, 8 ... 28) CUs of
- * every XCD are set aside; side 1 runs on those only, side 0 on all the others.  *cus_out = CUs the stream may use.
- * For frame pipelining: the HBM-bound T + V of frame k+1 on a few CUs beside the ALU-bound a-trous launches of
- * frame k on the rest (pass that CU count as rmd_svgf_params.atrous_cus). */
-int  rmd_stream_create_partition(void** stream, int reserve_per_xcd, int side, int* cus_out);
 int  rmd_stream_destroy(void* stream);
 int  rmd_stream_sync(void* stream);
 /* events order work across streams (frame pipelining): record on one stream, wait on another */
@@ -344,6 +339,11 @@ int  rmd_set_device(int device);
 int  rmd_print_device_properties(void);
 const char* rmd_last_error_string(void);
 const char* rmd_version(void);
+/* 1 if the library was built with -DRMD_EXPERIMENTS (`make experiments`: the a-trous formulations that were measured
+ * and lost -- atrous_variant 2, 4, 5, 6, 7, 8 --, the persistent T / V kernels behind tv_workgroups, and the
+ * environment tuning knobs of the measurement tools), 0 for the product library, where those settings return
+ * RMD_E_UNSUPPORTED. */
+int  rmd_has_experiments(void);
 
 /* HIP-event timing of a region on a stream (bench / harness). */
 int  rmd_timer_create(void** timer);

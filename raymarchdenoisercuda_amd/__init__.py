@@ -15,7 +15,13 @@ from .svgf import SvgfDenoiser, default_params
 
 __all__ = ["FilterParams", "GBuffer", "Int2", "LIB_PATH", "RmdError", "SvgfFrameDesc", "SvgfParams", "SynthDesc",
            "check", "last_error", "lib", "box_filter", "filterKernelBaseline", "filterKernelTiled", "make_gbuffer",
-           "sharding", "svgf", "SvgfDenoiser", "default_params"]
+           "sharding", "svgf", "SvgfDenoiser", "default_params", "HAS_EXPERIMENTS", "ATROUS_VARIANTS"]
+
+
+# a-trous formulations this build of librmd.so can run (include/rmd_api.h rmd_svgf_params.atrous_variant): the product
+# library has the default (0 = 3) and its direct cross-check (1); `make experiments` adds the ones that lost
+HAS_EXPERIMENTS = bool(lib.rmd_has_experiments())
+ATROUS_VARIANTS = (0, 1, 3) + ((2, 4, 5, 6, 7, 8) if HAS_EXPERIMENTS else ())
 
 
 def version():

@@ -133,7 +133,6 @@ SYMBOLS = {
     "rmd_host_alloc_pinned": (C.c_int, [C.POINTER(_P), C.c_size_t]),
     "rmd_host_free_pinned": (C.c_int, [_P]),
     "rmd_stream_create": (C.c_int, [C.POINTER(_P)]),
-    "rmd_stream_create_partition": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rmd_stream_destroy": (C.c_int, [_P]),
     "rmd_stream_sync": (C.c_int, [_P]),
     "rmd_event_create": (C.c_int, [C.POINTER(_P)]),
@@ -147,6 +146,7 @@ SYMBOLS = {
     "rmd_print_device_properties": (C.c_int, []),
     "rmd_last_error_string": (C.c_char_p, []),
     "rmd_version": (C.c_char_p, []),
+    "rmd_has_experiments": (C.c_int, []),
     "rmd_timer_create": (C.c_int, [C.POINTER(_P)]),
     "rmd_timer_destroy": (C.c_int, [_P]),
     "rmd_timer_start": (C.c_int, [_P, _P]),

@@ -295,7 +295,7 @@ static unsigned box_magic(int n)
 template <bool GRAY>
 static bool launch_box_stream(const uchar4* in, uchar4* out, int W, int H, int radius, hipStream_t stream)
 {
-    static const bool disabled = getenv("RMD_BOX_STREAM") && atoi(getenv("RMD_BOX_STREAM")) == 0;    // A/B knob
+    static const bool disabled = tuning_env("RMD_BOX_STREAM", 1) == 0;    // A/B knob (experiments build)
     if (disabled || radius < 1 || radius > 4 || (W & 3) || !aligned_to(in, 16) || !aligned_to(out, 16)) return false;
     const unsigned magic = box_magic((2 * radius + 1) * (2 * radius + 1));
     if (!magic) return false;
@@ -303,7 +303,7 @@ static bool launch_box_stream(const uchar4* in, uchar4* out, int W, int H, int r
     // Band height: the pass is latency-bound until the chip holds ~4 waves per SIMD, so aim for ~4096
     // waves (11 rows at 4K, 36 at 8K; measured at 4K: 6 rows 23.1 us, 11 rows 18.4, 16 rows 19.4) and
     // accept that a band re-reads the 2R halo rows its neighbours fetch too (served by L2 / Infinity Cache).
-    static const int band_env = getenv("RMD_BOX_BAND") ? atoi(getenv("RMD_BOX_BAND")) : 0;                // tuning knob
+    static const int band_env = tuning_env("RMD_BOX_BAND", 0);                // tuning knob (experiments build)
     int band_rows = (int)(((long long)H * nstrips + 4095) / 4096);
     band_rows = band_rows < 8 ? 8 : (band_rows > 64 ? 64 : band_rows);
     // the row loop runs in whole trips of U rows: make band + 2R a multiple of U (11 rows at 4K, radius 2)

@@ -44,6 +44,14 @@ int device_cus();                // multiProcessorCount of the current device (c
 // true exactly once per (device, key): guards per-device one-time calls such as hipFuncSetAttribute
 bool first_use_on_device(const void* key);
 
+// Kernel-tuning knobs (A/B switches of the measurement tools) are read from the environment ONLY in the
+// experiments build (-DRMD_EXPERIMENTS); the product library always runs its defaults.
+#ifdef RMD_EXPERIMENTS
+int tuning_env(const char* name, int dflt);
+#else
+inline int tuning_env(const char*, int dflt) { return dflt; }
+#endif
+
 // Plane geometry shared by the SVGF kernels: planes hold global rows
 // [buf_row0, buf_row0 + buf_rows) of a W x H frame.
 struct Geom {
@@ -61,9 +69,13 @@ int check_rows_in_buffer(const rmd_svgf_frame_desc* f, int lo, int hi, const cha
 // pixels and V returns at once from every unmarked tile.
 // FilterParams::type GAUSSIAN / CROSS / WAVELET on the uchar4 planes (csrc/weighted_filter.hip)
 int run_weighted_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStream_t stream);
-int launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
-int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused);
-// fused frame whose V pass is svgf_variance_tile_kernel: T then writes t_color only inside the tiles it flags
+// sparse_t_color: T writes t_color only inside the tiles it flags and V takes every other pixel of its windows from
+// v_color.  Decided ONCE per frame by the caller (variance_reads_sparse_t_color) and handed to both launchers;
+// launch_variance refuses it (RMD_E_PARAM) unless it runs the tile kernel, the only form that honours it.
+int launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused,
+                    bool sparse_t_color);
+int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused,
+                    bool sparse_t_color);
 bool variance_reads_sparse_t_color(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, bool fused);
 
 }  // namespace rmd

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(256) void f32_to_u8_kernel(const float4* __restrict
 // Demodulation: SVGF filters ILLUMINATION = radiance / albedo, so texture detail is not
 // blurred; the albedo is multiplied back in rmd_convert_f32_to_u8.  One IEEE division per channel (the
 // oracle's operation), the denominator floored at eps so black albedo does not produce infinities.
-__global__ __launch_bounds__(256) void demodulate_kernel(const float4* __restrict__ radiance, const float4* __restrict__ albedo,
-                                                         float4* __restrict__ out, size_t n, float eps)
+// radiance and out may be the same plane (rmd_api.h allows in == out): no __restrict__ on those two
+__global__ __launch_bounds__(256) void demodulate_kernel(const float4* radiance, const float4* __restrict__ albedo,
+                                                         float4* out, size_t n, float eps)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {

@@ -4,6 +4,7 @@
 // cudaDeviceSynchronize (src/test.cu:77,89) and printGPUProperties (src/utils.cpp:5-15).
 #include <cstdint>
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -80,6 +81,14 @@ int device_cus()
     return cus[d];
 }
 
+#ifdef RMD_EXPERIMENTS
+int tuning_env(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#endif
+
 bool first_use_on_device(const void* key)
 {
     static std::mutex mu;
@@ -104,7 +113,13 @@ using namespace rmd;
 extern "C" {
 
 const char* rmd_last_error_string(void) { return g_err; }
-const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.1 (gfx950)"; }
+#ifdef RMD_EXPERIMENTS
+const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.3 (gfx950, experiments build)"; }
+int rmd_has_experiments(void) { return 1; }
+#else
+const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.3 (gfx950)"; }
+int rmd_has_experiments(void) { return 0; }
+#endif
 
 int rmd_malloc(void** ptr, size_t bytes)
 {
@@ -184,33 +199,6 @@ int rmd_stream_create(void** stream)
     hipStream_t s;
     RMD_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     *stream = s;
-    return RMD_OK;
-}
-
-// A stream whose kernels run on a subset of the CUs.  `reserve_per_xcd` CUs of every XCD are set aside:
-// side 1 gets only those, side 0 everything else.  The mask removes the same number of CUs from every XCD
-// under both bit orders a driver may use for an 8-XCD device (bit = cu * 8 + xcd, or bit = xcd * 32 + cu):
-// bit i is reserved when (i % 8 + i / 32) % 8 < reserve_per_xcd / 4.  Workgroup dispatch stays round-robin
-// over the XCDs, so the XCD-aware tile orders of the kernels keep working on either side.
-int rmd_stream_create_partition(void** stream, int reserve_per_xcd, int side, int* cus_out)
-{
-    if (!stream) return fail(RMD_E_NULL, "rmd_stream_create_partition: stream is NULL");
-    const int cus = device_cus();
-    if (cus != kXcds * 32) return fail(RMD_E_PARAM, "rmd_stream_create_partition: written for %d XCDs x 32 CUs, device has %d CUs", kXcds, cus);
-    if (reserve_per_xcd < 4 || reserve_per_xcd > 28 || reserve_per_xcd % 4 != 0)
-        return fail(RMD_E_PARAM, "rmd_stream_create_partition: reserve_per_xcd %d must be a multiple of 4 in [4,28]", reserve_per_xcd);
-    if (side != 0 && side != 1) return fail(RMD_E_PARAM, "rmd_stream_create_partition: side %d is not 0 or 1", side);
-    uint32_t mask[8] = {};
-    int n = 0;
-    for (int i = 0; i < 256; ++i) {
-        // (i % 8 + i / 32) % 8 takes every value 0..7 four times per XCD under both bit orders
-        const bool reserved = ((i % 8) + (i / 32)) % 8 < reserve_per_xcd / 4;
-        if (reserved == (side == 1)) { mask[i / 32] |= 1u << (i % 32); ++n; }
-    }
-    hipStream_t s;
-    RMD_HIP(hipExtStreamCreateWithCUMask(&s, 8, mask));
-    *stream = s;
-    if (cus_out) *cus_out = n;
     return RMD_OK;
 }
 

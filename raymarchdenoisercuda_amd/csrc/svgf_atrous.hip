@@ -814,1484 +814,9 @@ extern "C" int rmd_debug_atrous_trace(unsigned long long* host_dst, int workgrou
 
 
 
-// =================================================================================== pair kernels
-// Second formulation (round 2).  tools/microbench/valu_issue.hip + valu_pairing.hip show that in a
-// mixed instruction stream EVERY VALU instruction of a wave64 costs one ~4.2-cycle issue slot of its
-// SIMD (transcendentals 8.2): plain v_fma/v_mul/v_add only run two-per-slot when two waves issue
-// nothing else, which a real kernel never does.  So the cost of a step is its instruction COUNT, and a
-// packed v_pk_*_f32 (two pixels per slot) halves every operation it can express.  Hence:
-//   - a lane owns two HORIZONTALLY adjacent output pixels (x, x+1), x even.  Both see every tap at
-//     the same offset (dx, dy): same B3 weight, same length class, no tap rows that only one of the
-//     two uses -- all 24 off-centre taps run the same 16 + 4 instruction body;
-//   - LDS holds the staged rows as 8 planes (l, r, g, var, nx, ny, nz, z) of floats, so the values of
-//     the taps of the two pixels (columns c, c+1) are ONE aligned ds_read_b64 = one register pair;
-//   - cosine (3), sigma_n*log2(cos)+log2 k (1), the two differences (2) and the five accumulations
-//     (6) are packed; only the two |.|-modified fmas per pixel (packed f32 has no abs) stay scalar;
-//   - the centre tap is the constant k(0,0) = 9/64 (w_n = 1, dz = dl = 0): no transcendental.
-// Per-pixel order of summation is plain dx outer / dy inner (the oracle's), identical in the direct
-// variant below, so the two stay bit-identical for every decomposition.
-
-template <class T> struct TapT { T l, r, g, v, nx, ny, nz, z; };
-template <class T> struct CenterT { T nx, ny, nz, z, l, il; T iz[5]; T zc; };   // zc = 1 if the centre normal is (0,0,0), else 0
-template <class T> struct AccT { T sw, sl, sr, sg, sv; };
-
-__device__ __forceinline__ float splat(float v, float) { return v; }
-__device__ __forceinline__ f2    splat(float v, f2) { return f2{ v, v }; }
-__device__ __forceinline__ float fma_clamp01(float a, float b, float c) { return clamp01(fma_(a, b, c)); }
-__device__ __forceinline__ f2    fma_clamp01(f2 a, f2 b, f2 c)
-{
-    f2 r;   // the compiler folds a clamp only into scalar fmas
-    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-// e = c - |dz|*iz - |dl|*il, scalar per pixel on purpose (abs/neg are free source modifiers of v_fma_f32)
-__device__ __forceinline__ float edge_terms(float c, float dz, float iz, float dl, float il)
-{
-    return fma_(-fabsf(dl), il, fma_(-fabsf(dz), iz, c));
-}
-__device__ __forceinline__ f2 edge_terms(f2 c, f2 dz, f2 iz, f2 dl, f2 il)
-{
-    return f2{ edge_terms(c.x, dz.x, iz.x, dl.x, il.x), edge_terms(c.y, dz.y, iz.y, dl.y, il.y) };
-}
-
-// One off-centre tap for one pixel (T = float) or for the pixel pair (T = f2).  ZA (zero-aware): the
-// wave holds a centre whose normal is (0,0,0) (Appendix A.A.2: both zero => w_n = 1, exactly one zero
-// => 0).  With ft = 1 - n_t.n_t (1 for a zero tap normal, ~0 for a unit one) the cosine becomes
-// clamp01(n_p.n_t + zc*ft): unchanged bits for zc = 0, ft for a zero centre.
-template <class T, bool ZA>
-__device__ __forceinline__ void tap_eval(AccT<T>& s, const CenterT<T>& k, const TapT<T>& t, const T e0, const int cls, const T sigma_n)
-{
-    T d = k.nx * t.nx;
-    d = fma_(k.ny, t.ny, d);
-    T cosine;
-    if (ZA) {
-        T ft = fma_(-t.nx, t.nx, splat(1.0f, T{}));
-        ft = fma_(-t.ny, t.ny, ft);
-        ft = fma_(-t.nz, t.nz, ft);
-        d = fma_(k.nz, t.nz, d);
-        cosine = fma_clamp01(k.zc, ft, d);
-    } else {
-        cosine = fma_clamp01(k.nz, t.nz, d);
-    }
-    const T c = fma_(sigma_n, log2_(cosine), e0);
-    const T e = edge_terms(c, k.z - t.z, k.iz[cls], k.l - t.l, k.il);
-    const T w = exp2_(e);
-    s.sw += w;
-    s.sl = fma_(w, t.l, s.sl);
-    s.sr = fma_(w, t.r, s.sr);
-    s.sg = fma_(w, t.g, s.sg);
-    s.sv = fma_(w * w, t.v, s.sv);
-}
-// the centre tap: w = k(0,0) = 9/64 exactly
-template <class T>
-__device__ __forceinline__ void tap_center(AccT<T>& s, const T l, const T r, const T g, const T v)
-{
-    const T w = splat(0.140625f, T{});
-    s.sw += w;
-    s.sl = fma_(w, l, s.sl);
-    s.sr = fma_(w, r, s.sr);
-    s.sg = fma_(w, g, s.sg);
-    s.sv = fma_(w * w, v, s.sv);
-}
-
-template <class T> __device__ __forceinline__ T max0(T x);
-template <> __device__ __forceinline__ float max0<float>(float x) { return x > 0.0f ? x : 0.0f; }
-template <> __device__ __forceinline__ f2 max0<f2>(f2 x) { return f2{ max0<float>(x.x), max0<float>(x.y) }; }
-__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ f2    sqrt_(f2 x) { return f2{ sqrt_(x.x), sqrt_(x.y) }; }
-__device__ __forceinline__ float rcp_(float x) { return fast_rcp(x); }
-__device__ __forceinline__ f2    rcp_(f2 x) { return f2{ fast_rcp(x.x), fast_rcp(x.y) }; }
-__device__ __forceinline__ float maxf_(float a, float b) { return fmaxf(a, b); }
-__device__ __forceinline__ f2    maxf_(f2 a, float b) { return f2{ fmaxf(a.x, b), fmaxf(a.y, b) }; }
-
-// per-pixel constants from the centre values, the prefiltered variance and the depth gradient
-// (same operations as make_center above)
-template <class T>
-__device__ __forceinline__ void center_consts(CenterT<T>& k, const T var_c, const T gz, const float sigma_z, const float sigma_l, const float step)
-{
-    constexpr float kInvLog2e = 1.0f / kLog2e, kEps = 1e-8f / kLog2e;
-    k.il = rcp_(fma_(splat(sigma_l * kInvLog2e, T{}), sqrt_(max0<T>(var_c)), splat(kEps, T{})));
-    const T za = maxf_(gz, 1e-8f) * splat(sigma_z, T{}) * splat(step, T{});
-    k.iz[0] = rcp_(fma_(za, splat(1.0f * kInvLog2e, T{}), splat(kEps, T{})));
-    k.iz[1] = rcp_(fma_(za, splat(1.41421356237309504880f * kInvLog2e, T{}), splat(kEps, T{})));
-    k.iz[2] = rcp_(fma_(za, splat(2.0f * kInvLog2e, T{}), splat(kEps, T{})));
-    k.iz[3] = rcp_(fma_(za, splat(2.23606797749978969641f * kInvLog2e, T{}), splat(kEps, T{})));
-    k.iz[4] = rcp_(fma_(za, splat(2.82842712474619009760f * kInvLog2e, T{}), splat(kEps, T{})));
-}
-
-// A.A.3 for one pixel; c = (l, r, g, var) of the centre.  Blue is recovered from the luminance sum and
-// clamped at 0 (the recovery amplifies the rounding of L by 1/0.0722; a true blue of 0 must not turn
-// into a small negative history value).
-__device__ __forceinline__ float4 finish2(float sw, float sl, float sr, float sg, float sv, float cl, float cr, float cg, float cv)
-{
-    float L, R, G, V;
-    if (sw < 1e-10f) { L = cl; R = cr; G = cg; V = cv; }
-    else {
-        const float inv = fast_rcp(sw);
-        L = sl * inv; R = sr * inv; G = sg * inv; V = sv * inv * inv;
-    }
-    const float B = fmaxf(fma_(-kLumG, G, fma_(-kLumR, R, L)) * (1.0f / kLumB), 0.0f);
-    return make_float4(R, G, B, V);
-}
-
-// ------------------------------------------------------------------------- direct (pair arithmetic)
-// One thread per pixel, taps from global memory, the arithmetic of the pair kernel with T = float.
-__global__ __launch_bounds__(256) void atrous_direct2_kernel(AtrousArgs a)
-{
-    const Geom g = a.g;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = a.row0 + blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= g.W || y >= a.row1) return;
-    const int s = a.step;
-    const size_t i = pix_index(g, x, y);
-    const float4 cc = to_lrgv(a.in[i]);
-    const float4 cn = a.nd[i];
-
-    float var_c;
-    const bool okl = x - 1 >= 0, okr = x + 1 < g.W, oku = y - 1 >= 0, okd = y + 1 < g.H;
-    auto var_at = [&](int tx, int ty) { return a.in[pix_index(g, tx, ty)].w; };
-    if (okl && okr && oku && okd) {
-        var_c = prefilter9(var_at(x - 1, y - 1), var_at(x - 1, y), var_at(x - 1, y + 1), var_at(x, y - 1), cc.w,
-                           var_at(x, y + 1), var_at(x + 1, y - 1), var_at(x + 1, y), var_at(x + 1, y + 1));
-    } else {
-        float gs = 0.25f, vs = 0.25f * cc.w;
-        if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x - 1, y - 1), vs); }
-        if (okl)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x - 1, y), vs); }
-        if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x - 1, y + 1), vs); }
-        if (oku)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x, y - 1), vs); }
-        if (okd)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x, y + 1), vs); }
-        if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x + 1, y - 1), vs); }
-        if (okr)        { gs += 0.125f;  vs = fma_(0.125f, var_at(x + 1, y), vs); }
-        if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, var_at(x + 1, y + 1), vs); }
-        var_c = vs / gs;
-    }
-    const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
-    const float gz = fabsf(a.nd[pix_index(g, x1, y)].w - cn.w) + fabsf(a.nd[pix_index(g, x, y1)].w - cn.w);
-    CenterT<float> k;
-    k.nx = cn.x; k.ny = cn.y; k.nz = cn.z; k.z = cn.w; k.l = cc.x;
-    k.zc = is_zero3(cn) ? 1.0f : 0.0f;
-    center_consts<float>(k, var_c, gz, a.sigma_z, a.sigma_l, (float)s);
-
-    AccT<float> acc = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-    for (int dx = -2; dx <= 2; ++dx) {
-#pragma unroll
-        for (int dy = -2; dy <= 2; ++dy) {
-            if (dx == 0 && dy == 0) { tap_center<float>(acc, cc.x, cc.y, cc.z, cc.w); continue; }
-            const int tx = x + s * dx, ty = y + s * dy;
-            if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
-            const size_t ti = pix_index(g, tx, ty);
-            const float4 tc = to_lrgv(a.in[ti]);
-            const float4 tn = a.nd[ti];
-            const TapT<float> t = { tc.x, tc.y, tc.z, tc.w, tn.x, tn.y, tn.z, tn.w };
-            const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-            tap_eval<float, true>(acc, k, t, kLogB3[adx] + kLogB3[ady], len_class(adx, ady), a.sigma_n);
-        }
-    }
-    a.out[i] = finish2(acc.sw, acc.sl, acc.sr, acc.sg, acc.sv, cc.x, cc.y, cc.z, cc.w);
-}
-
-// ------------------------------------------------------------------------- pair stream kernel
-template <int S>
-struct PairCfg {
-    static constexpr int CW = 128;                    // output columns per workgroup: 64 lanes x 2 pixels
-    static constexpr int PW = CW + 4 * S;             // staged row width (halo 2S each side), even
-    static constexpr int NR = 8, ADV = 4;             // ring rows j-2 .. j+5; a step yields rows j .. j+3 (one per wave)
-    // A staged row is 4 "pair planes" (l,r) (g,var) (nx,ny) (nz,z); a plane is PW/2 elements of 16 bytes,
-    // element m = [a(2m) a(2m+1) b(2m) b(2m+1)]: one conflict-free ds_read_b128 per lane yields the
-    // register pairs (a, a') and (b, b') of the two pixels of a lane for two of the eight tap values.
-    static constexpr int PLANE = PW * 8;              // bytes of one pair plane of one staged row
-    static constexpr int ROW_BYTES = 4 * PLANE;
-    static constexpr int RING_BYTES = NR * ROW_BYTES;
-    static constexpr int AUXW = CW + 4;               // aux row: columns x0-2 .. x0+CW+1 (pairs stay 8-byte aligned)
-    static constexpr int AUX_ROW = AUXW * 4;
-    static constexpr int AUX_OFF = RING_BYTES;        // per output row of the step: var(y-1), var(y+1)
-    static constexpr int LDS_BYTES = AUX_OFF + ADV * 2 * AUX_ROW;
-    static constexpr int WG_PER_CU = 3;
-};
-
-// volatile: keeps the compiler from fusing or hoisting the tap reads (the address space is spelled out: a
-// volatile access through a generic pointer would become a flat load)
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef const volatile __attribute__((address_space(3))) f4v lds_quad;
-typedef const volatile __attribute__((address_space(3))) f2 lds_pair;
-typedef const __attribute__((address_space(3))) float lds_scalar;
-struct TwoPairs { f2 a, b; };
-__device__ __forceinline__ TwoPairs lds_quad_at(const unsigned char* lds, int off)
-{
-    const f4v q = *(lds_quad*)(lds + off);
-    return TwoPairs{ f2{ q.x, q.y }, f2{ q.z, q.w } };
-}
-__device__ __forceinline__ f2 lds_f2(const unsigned char* lds, int off) { return *(lds_pair*)(lds + off); }
-// two floats 12 bytes apart: the values of columns (c, c+1), c odd, of one of the two planes of a pair plane
-// (element m-1 slot 1 and element m slot 0); the compiler fuses the two loads into one ds_read2_b32
-__device__ __forceinline__ f2 lds_odd_pair(const unsigned char* lds, int off)
-{
-    lds_scalar* p = (lds_scalar*)(lds + off);
-    return f2{ p[0], p[3] };
-}
-// two adjacent floats at a 4-byte aligned address (aux rows)
-__device__ __forceinline__ f2 lds_f2u(const unsigned char* lds, int off)
-{
-    lds_scalar* p = (lds_scalar*)(lds + off);
-    return f2{ p[0], p[1] };
-}
-
-// XE: the strip touches the left / right frame border (per-lane column tests).  Rows are handled the
-// same way in both forms, with wave-uniform tests only: rows outside the frame (or the buffer) are
-// staged as zeros, and the two lattice rows next to the top / bottom border take the generic prefilter.
-template <int S, bool XE>
-__device__ __forceinline__ void atrous_pair_body(const AtrousArgs& a, unsigned char* lds, const int tid,
-                                                 const int x0, const int ybase, const int jlo, const int jhi)
-{
-    using C = PairCfg<S>;
-    const Geom g = a.g;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave = output row of the step
-    const int xA = x0 + 2 * lane;                                  // pixels xA, xA + 1
-    const bool inA = !XE || xA < g.W, inB = !XE || xA + 1 < g.W;
-    const float* in_f = reinterpret_cast<const float*>(a.in);
-    const float* nd_f = reinterpret_cast<const float*>(a.nd);
-    const int blo = max(g.buf_row0, 0), bhi = min(g.buf_row0 + g.buf_rows, g.H);   // rows that exist
-
-    auto slot_of = [&](const int j) { return (j + 4 * C::NR) % C::NR; };        // j >= -2
-
-    // ---- staging: a refill brings ADV lattice rows (jb .. jb+3); wave wv stages row jb + wv, lane ->
-    // columns lane, lane + 64, lane + 128 of the PW staged columns.  Everything that depends on the row is
-    // wave-uniform (scalar unit), everything that depends on the lane is a loop constant: a refill costs
-    // no vector address arithmetic.  Loads are UNCONDITIONAL at clamped addresses (a load inside a branch
-    // makes the compiler drain the whole prefetch queue with vmcnt(0) at the join).  A pixel outside the
-    // frame or the buffer only has to present a zero normal: its taps then weigh exactly 0 (log2 0 = -inf)
-    // and the finite colour / depth values fetched from the clamped address are multiplied by that 0.
-    static_assert(C::PW > 128 && C::PW <= 192, "three 64-lane passes cover a staged row");
-    int gofs[3];                   // pixel offset inside a row of the frame (clamped to the frame in the XE form)
-    float keepx[3];                // XE: 0 for a column outside the frame
-    int sofs[3];                   // byte offset of the staged column inside a pair plane (element col/2, slot col&1)
-    bool sact[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int col = lane + 64 * q;
-        sact[q] = col < C::PW;
-        const int colc = min(col, C::PW - 1);
-        const int gx = x0 - 2 * S + colc;
-        keepx[q] = (!XE || (gx >= 0 && gx < g.W)) ? 1.0f : 0.0f;
-        gofs[q] = XE ? min(max(gx, 0), g.W - 1) : gx;
-        sofs[q] = (colc >> 1) * 16 + (colc & 1) * 4;
-    }
-    float4 pc[3], pn[3];
-    bool prow_ok = true;           // wave-uniform: the row being prefetched exists
-    const float4 *prc = a.in, *prn = a.nd;
-    auto begin_rows = [&](const int jb) {          // scalar part of a refill: row pointers
-        const int y = ybase + (jb + wv) * S;
-        prow_ok = y >= blo && y < bhi;
-        const int yc = min(max(y, blo), bhi - 1);
-        prc = a.in + (size_t)(yc - g.buf_row0) * (size_t)g.W;
-        prn = a.nd + (size_t)(yc - g.buf_row0) * (size_t)g.W;
-    };
-    auto load_rows_piece = [&](const int i) {      // i = 0..5: one vector-memory instruction each
-        if (i & 1) pn[i >> 1] = prn[gofs[i >> 1]]; else pc[i >> 1] = prc[gofs[i >> 1]];
-    };
-    auto store_rows = [&](const int jb) {
-        unsigned char* row = lds + slot_of(jb + wv) * C::ROW_BYTES;
-        const float krow = prow_ok ? 1.0f : 0.0f;
-        constexpr int PF = C::PLANE / 4;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            if (sact[q]) {
-                float* p = reinterpret_cast<float*>(row + sofs[q]);
-                float nx = pn[q].x, ny = pn[q].y, nz = pn[q].z;
-                if (XE || !prow_ok) { const float kk = XE ? krow * keepx[q] : krow; nx *= kk; ny *= kk; nz *= kk; }
-                p[0 * PF] = lum3(pc[q].x, pc[q].y, pc[q].z); p[0 * PF + 2] = pc[q].x;
-                p[1 * PF] = pc[q].y;                          p[1 * PF + 2] = pc[q].w;
-                p[2 * PF] = nx;                               p[2 * PF + 2] = ny;
-                p[3 * PF] = nz;                               p[3 * PF + 2] = pn[q].w;
-            }
-        }
-    };
-    // aux rows of the outputs of step jo (wave wv serves its own output row): variance of rows y-1, y+1 at
-    // columns x0-2 .. x0+CW+1 (lane -> two columns, lanes 0..3 the last four), staged through LDS for the
-    // 3x3 prefilter; z of row y+1 at the lane's own two pixels stays in registers (depth gradient).
-    // Unconditional loads at clamped rows / columns: the prefilter and the gradient test which of these
-    // values exist (oku / okd / okl / okr), rows of dropped outputs read something harmless.
-    // lane -> ONE column per gather (16-byte lane stride: a gather instruction then touches 1 KB, not 2)
-    int aofs[3], zofs[2];          // float offsets inside a frame row: var of columns x0-2+lane, +64, the 4 tail columns; z of xA, xA+1
-    {
-        const int g0 = x0 - 2 + lane, g1 = g0 + 64, g2 = x0 + C::CW - 2 + (lane & 3);
-        aofs[0] = (XE ? min(max(g0, 0), g.W - 1) : g0) * 4 + 3;
-        aofs[1] = (XE ? min(max(g1, 0), g.W - 1) : g1) * 4 + 3;
-        aofs[2] = (XE ? min(max(g2, 0), g.W - 1) : g2) * 4 + 3;
-        zofs[0] = (XE ? min(xA, g.W - 1) : xA) * 4 + 3;
-        zofs[1] = (XE ? min(xA + 1, g.W - 1) : xA + 1) * 4 + 3;
-    }
-    float pau[2][2], pax[2];
-    f2 zd_cur = f2{ 0.0f, 0.0f }, zd_next = zd_cur;
-    const float *pup = in_f, *pdn = in_f, *pzr = nd_f;
-    auto begin_aux = [&](const int jo) {
-        const int y = min(max(ybase + (jo + wv) * S, blo), bhi - 1);
-        const int yu = max(y - 1, blo), yd = min(y + 1, bhi - 1);
-        pup = in_f + (size_t)(yu - g.buf_row0) * (size_t)g.W * 4;
-        pdn = in_f + (size_t)(yd - g.buf_row0) * (size_t)g.W * 4;
-        pzr = nd_f + (size_t)(yd - g.buf_row0) * (size_t)g.W * 4;
-    };
-    auto load_aux_piece = [&](const int i) {       // i = 0..7: one vector-memory instruction each
-        switch (i) {
-            case 0: pau[0][0] = pup[aofs[0]]; break;
-            case 1: pau[1][0] = pup[aofs[1]]; break;
-            case 2: pax[0] = pup[aofs[2]]; break;
-            case 3: pau[0][1] = pdn[aofs[0]]; break;
-            case 4: pau[1][1] = pdn[aofs[1]]; break;
-            case 5: pax[1] = pdn[aofs[2]]; break;
-            case 6: zd_next.x = pzr[zofs[0]]; break;
-            default: zd_next.y = pzr[zofs[1]]; break;
-        }
-    };
-    auto store_aux = [&]() {
-        float* ax = reinterpret_cast<float*>(lds + C::AUX_OFF + wv * 2 * C::AUX_ROW);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            ax[k * C::AUXW + lane] = pau[0][k];
-            ax[k * C::AUXW + 64 + lane] = pau[1][k];
-            if (lane < 4) ax[k * C::AUXW + C::CW + lane] = pax[k];
-        }
-        zd_cur = zd_next;
-    };
-
-    float4 outA, outB;
-    // ---- one step: this wave produces lattice row jw = j + wv, this lane its pixels xA, xA+1
-    auto compute = [&](const int j) {
-        const int jw = j + wv;
-        const int y = ybase + jw * S;
-        // The 14 vector-memory instructions of the next refill (6 row loads, 8 aux gathers) are issued ONE PER
-        // TAP inside the tap loop: issued together at the top of a step they queue up in the CU's one texture
-        // address unit (4 waves x 14 at once after the barrier) and every wave stalls at issue -- a quarter of
-        // the step.  They are unconditional (clamped rows): the last step fetches rows it does not use.
-        begin_rows(j + 6);
-        begin_aux(j + C::ADV);
-        int rb[5];
-#pragma unroll
-        for (int tr = 0; tr < 5; ++tr) rb[tr] = slot_of(jw - 2 + tr) * C::ROW_BYTES + (S + lane) * 16;   // element of columns xA, xA+1 of tap row tr
-        const int cb = rb[2];
-        CenterT<f2> k;
-        const f2 cv = lds_f2(lds, cb + 1 * C::PLANE + 8);         // (l, r, g are re-read where they are needed: centre tap, finish)
-        { const TwoPairs q = lds_quad_at(lds, cb + 2 * C::PLANE); k.nx = q.a; k.ny = q.b; }
-        { const TwoPairs q = lds_quad_at(lds, cb + 3 * C::PLANE); k.nz = q.a; k.z = q.b; }
-        k.l = lds_f2(lds, cb + 0 * C::PLANE);
-        const bool zA = k.nx.x == 0.0f && k.ny.x == 0.0f && k.nz.x == 0.0f, zB = k.nx.y == 0.0f && k.ny.y == 0.0f && k.nz.y == 0.0f;
-        k.zc = f2{ zA ? 1.0f : 0.0f, zB ? 1.0f : 0.0f };
-
-        // A.A.1: 3x3 prefilter of the variance.  Columns xA-1 .. xA+2 of rows y-1 (aux), y (ring), y+1 (aux)
-        const unsigned char* axb = lds + C::AUX_OFF + wv * 2 * C::AUX_ROW + lane * 8;    // aux column xA-2
-        const f2 vu_l = lds_f2u(axb, 0 * C::AUX_ROW + 4), vu_c = lds_f2(axb, 0 * C::AUX_ROW + 8), vu_r = lds_f2u(axb, 0 * C::AUX_ROW + 12);
-        const f2 vd_l = lds_f2u(axb, 1 * C::AUX_ROW + 4), vd_c = lds_f2(axb, 1 * C::AUX_ROW + 8), vd_r = lds_f2u(axb, 1 * C::AUX_ROW + 12);
-        const f2 vm_l = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 - 12), vm_r = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 + 4);   // var of (xA-1, xA), (xA+1, xA+2)
-        f2 zr = lds_odd_pair(lds, cb + 3 * C::PLANE + 8 + 4);     // z of columns xA+1, xA+2
-        const f2 zd = zd_cur;                                     // z of row y+1, columns xA, xA+1
-        const bool oku = y - 1 >= 0, okd = y + 1 < g.H;           // wave-uniform
-        f2 var_c;
-        if (!XE && oku && okd) {
-            f2 v = splat(0.0625f, f2{}) * vu_l;
-            v = fma_(splat(0.125f, f2{}), vm_l, v);  v = fma_(splat(0.0625f, f2{}), vd_l, v);
-            v = fma_(splat(0.125f, f2{}), vu_c, v);  v = fma_(splat(0.25f, f2{}), cv, v);   v = fma_(splat(0.125f, f2{}), vd_c, v);
-            v = fma_(splat(0.0625f, f2{}), vu_r, v); v = fma_(splat(0.125f, f2{}), vm_r, v); v = fma_(splat(0.0625f, f2{}), vd_r, v);
-            var_c = v;
-        } else {
-            // frame borders: renormalised prefilter (same operations as the direct kernel)
-            float vcs[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int x = xA + i;
-                const bool okl = !XE || x - 1 >= 0, okr = !XE || x + 1 < g.W;
-                const float ul = i ? vu_l.y : vu_l.x, uc = i ? vu_c.y : vu_c.x, ur = i ? vu_r.y : vu_r.x;
-                const float dl = i ? vd_l.y : vd_l.x, dc = i ? vd_c.y : vd_c.x, dr = i ? vd_r.y : vd_r.x;
-                const float ml = i ? vm_l.y : vm_l.x, mr = i ? vm_r.y : vm_r.x, mc = i ? cv.y : cv.x;
-                if (okl && okr && oku && okd) { vcs[i] = prefilter9(ul, ml, dl, uc, mc, dc, ur, mr, dr); continue; }
-                float gs = 0.25f, vs = 0.25f * mc;
-                if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, ul, vs); }
-                if (okl)        { gs += 0.125f;  vs = fma_(0.125f, ml, vs); }
-                if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, dl, vs); }
-                if (oku)        { gs += 0.125f;  vs = fma_(0.125f, uc, vs); }
-                if (okd)        { gs += 0.125f;  vs = fma_(0.125f, dc, vs); }
-                if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, ur, vs); }
-                if (okr)        { gs += 0.125f;  vs = fma_(0.125f, mr, vs); }
-                if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, dr, vs); }
-                vcs[i] = vs / gs;
-            }
-            var_c = f2{ vcs[0], vcs[1] };
-        }
-        if (XE) {
-            if (xA + 1 >= g.W) zr.x = k.z.x;
-            if (xA + 2 >= g.W) zr.y = k.z.y;
-        }
-        const f2 gz = f2{ fabsf(zr.x - k.z.x) + fabsf(zd.x - k.z.x), fabsf(zr.y - k.z.y) + fabsf(zd.y - k.z.y) };
-        center_consts<f2>(k, var_c, gz, a.sigma_z, a.sigma_l, (float)S);
-
-        bool rowv[5];
-#pragma unroll
-        for (int tr = 0; tr < 5; ++tr) {
-            const int yy = y + (tr - 2) * S;
-            rowv[tr] = yy >= 0 && yy < g.H;
-        }
-        // the zero-aware body only where a VALID centre of this wave has a zero normal
-        const bool any_zero = __builtin_amdgcn_ballot_w64((zA && inA) || (zB && inB)) != 0ull;
-        float sn = a.sigma_n;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));   // VGPR on purpose: leaves the one SGPR operand slot of v_pk_fma_f32 to log2 k
-        const f2 sn2 = splat(sn, f2{});
-        AccT<f2> acc = { f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
-
-        auto load_tap = [&](const int ti, TapT<f2>& t) {
-            const int dxi = ti / 5, tr = ti % 5;
-            const int sdx = (dxi - 2) * S;                        // column offset of the tap
-            if ((sdx & 1) == 0) {
-                const int off = rb[tr] + (sdx / 2) * 16;
-                { const TwoPairs q = lds_quad_at(lds, off + 0 * C::PLANE); t.l = q.a; t.r = q.b; }
-                { const TwoPairs q = lds_quad_at(lds, off + 1 * C::PLANE); t.g = q.a; t.v = q.b; }
-                { const TwoPairs q = lds_quad_at(lds, off + 2 * C::PLANE); t.nx = q.a; t.ny = q.b; }
-                { const TwoPairs q = lds_quad_at(lds, off + 3 * C::PLANE); t.nz = q.a; t.z = q.b; }
-            } else {          // S = 1, dx = -1 / +1: the pair (xA+dx, xA+dx+1) starts on an odd column
-                const int off = rb[tr] + ((sdx - 1) / 2) * 16 + 4;    // slot 1 of the element that holds column xA+dx
-                t.l = lds_odd_pair(lds, off + 0 * C::PLANE);  t.r = lds_odd_pair(lds, off + 0 * C::PLANE + 8);
-                t.g = lds_odd_pair(lds, off + 1 * C::PLANE);  t.v = lds_odd_pair(lds, off + 1 * C::PLANE + 8);
-                t.nx = lds_odd_pair(lds, off + 2 * C::PLANE); t.ny = lds_odd_pair(lds, off + 2 * C::PLANE + 8);
-                t.nz = lds_odd_pair(lds, off + 3 * C::PLANE); t.z = lds_odd_pair(lds, off + 3 * C::PLANE + 8);
-            }
-        };
-        auto taps = [&](auto zero_aware) {
-            constexpr bool ZA = decltype(zero_aware)::value;
-            auto weigh = [&](const int ti, const TapT<f2>& t) {
-                const int dx = ti / 5 - 2, dy = ti % 5 - 2;
-                const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-                if (dx == 0 && dy == 0) {
-                    const TwoPairs lr = lds_quad_at(lds, cb + 0 * C::PLANE), gv = lds_quad_at(lds, cb + 1 * C::PLANE);
-                    tap_center<f2>(acc, lr.a, lr.b, gv.a, gv.b);
-                    return;
-                }
-                // Out-of-frame taps are staged as zeros: a zero tap normal gives cos = 0, log2 = -inf and
-                // weight exactly 0 for a non-zero centre.  A zero centre would accept them (zero pairs with
-                // zero), so the zero-aware body masks them explicitly.
-                f2 e0 = splat(kLogB3[adx] + kLogB3[ady], f2{});
-                if (ZA) {
-                    bool okA = rowv[dy + 2], okB = okA;
-                    if (XE) {
-                        okA = okA && xA + dx * S >= 0 && xA + dx * S < g.W;
-                        okB = okB && xA + 1 + dx * S >= 0 && xA + 1 + dx * S < g.W;
-                    }
-                    e0 = f2{ okA ? e0.x : kNegInf, okB ? e0.y : kNegInf };
-                }
-                tap_eval<f2, ZA>(acc, k, t, e0, len_class(adx, ady), sn2);
-            };
-            // the 24 off-centre taps in dx-outer / dy-inner order, double-buffered: the reads of tap q+1 are
-            // issued before tap q is weighted; the centre tap (needs no fetch) sits between q = 11 and 12
-            TapT<f2> t0, t1;
-            load_tap(0, t0);
-#pragma unroll
-            for (int q = 0; q < 24; ++q) {
-                const int ti = q < 12 ? q : q + 1, tn = q + 1 < 12 ? q + 1 : q + 2;
-                if (q == 12) weigh(12, t0);
-                // the reads of the next tap go out BEFORE anything of this tap is weighted (left to itself the
-                // scheduler sinks them behind the logarithms, half a tap before their use)
-                if (q < 23) { if (q & 1) load_tap(tn, t0); else load_tap(tn, t1); }
-                if (q < 6) load_rows_piece(q); else if (q < 14) load_aux_piece(q - 6);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q & 1) weigh(ti, t1); else weigh(ti, t0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
-        const TwoPairs flr = lds_quad_at(lds, cb + 0 * C::PLANE), fgv = lds_quad_at(lds, cb + 1 * C::PLANE);
-        const f2 fl = flr.a, fr = flr.b, fg = fgv.a, fv = fgv.b;
-        outA = finish2(acc.sw.x, acc.sl.x, acc.sr.x, acc.sg.x, acc.sv.x, fl.x, fr.x, fg.x, fv.x);
-        outB = finish2(acc.sw.y, acc.sl.y, acc.sr.y, acc.sg.y, acc.sv.y, fl.y, fr.y, fg.y, fv.y);
-    };
-    auto write_out = [&](const int j) {
-        const int jw = j + wv;
-        if (jw >= jlo && jw < jhi) {
-            float4* o = a.out + (size_t)(ybase + jw * S - g.buf_row0) * (size_t)g.W + (size_t)xA;
-            if (inA) o[0] = outA;
-            if (inB) o[1] = outB;
-        }
-    };
-
-    // ---- prologue: ring rows j0-2 .. j0+5 and the aux rows of the first step
-    const int j0 = jlo & ~3;
-    auto load_rows = [&](const int jb) { begin_rows(jb); for (int i = 0; i < 6; ++i) load_rows_piece(i); };
-    load_rows(j0 - 2);
-    store_rows(j0 - 2);
-    load_rows(j0 + 2);
-    begin_aux(j0);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) load_aux_piece(i);
-    store_rows(j0 + 2);
-    store_aux();
-    __syncthreads();
-
-    const int span = jhi - j0;
-    const int jq1 = j0 + span * RMD_PRIO_T1 / 16, jq2 = j0 + span * RMD_PRIO_T2 / 16, jq3 = j0 + span * RMD_PRIO_T3 / 16;
-    __builtin_amdgcn_s_setprio(3);
-#ifdef RMD_ATROUS_TRACE
-    unsigned long long ph[5] = { 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
+#ifdef RMD_EXPERIMENTS
+#include "experiments/atrous_variants.inc"
 #endif
-    for (int j = j0; j < jhi; j += C::ADV) {
-        if (j >= jq3)      __builtin_amdgcn_s_setprio(0);
-        else if (j >= jq2) __builtin_amdgcn_s_setprio(1);
-        else if (j >= jq1) __builtin_amdgcn_s_setprio(2);
-        const bool more = j + C::ADV < jhi;
-        RMD_PHASE(0)
-        compute(j);
-        RMD_PHASE(1)
-        if (!more) { write_out(j); break; }
-        __syncthreads();                                     // every wave is done reading rows j-2 .. j+1 and the aux rows
-        RMD_PHASE(2)
-        store_rows(j + 6); store_aux();
-        write_out(j);
-        RMD_PHASE(3)
-        __syncthreads();
-        RMD_PHASE(4)
-    }
-#ifdef RMD_ATROUS_TRACE
-    if (tid == 0 && blockIdx.x < 8192)
-        for (int i = 0; i < 5; ++i) g_atrous_phase[8 * blockIdx.x + i] = ph[i];
-#endif
-}
-
-template <int S>
-__global__ __launch_bounds__(256, 3) void atrous_pair_kernel(AtrousArgs a)
-{
-    using C = PairCfg<S>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char atrous_lds[];
-    const int tid = threadIdx.x;
-    const int pid = blockIdx.x;
-    // XCD-aware order: workgroups pid, pid+8, ... share an XCD (round-robin dispatch).  Each XCD gets one
-    // contiguous run of the interior work (neighbouring strips / lattices share halo columns and the +-1
-    // variance rows in its L2) followed by its share of the border-strip work.
-    const int xcd = pid & (kXcds - 1), slot = pid >> 3;
-    int L;
-    if (slot < a.int_per_xcd) { L = xcd * a.int_per_xcd + slot; if (L >= a.total_int) return; }
-    else { L = a.total_int + xcd * a.xe_per_xcd + (slot - a.int_per_xcd); if (L >= a.nblocks) return; }
-    // interior strips first (band height band_h), then the border strips (band_h_xe)
-    int strip, band, r, bh;
-    if (L < a.total_int) {
-        r = L % S; const int t = L / S;
-        strip = a.xe_lo + t % a.n_int; band = t / a.n_int; bh = a.band_h;
-    } else {
-        const int Lx = L - a.total_int, nxe = a.nstrips - a.n_int;
-        r = Lx % S; const int t = Lx / S, e = t % nxe;
-        strip = e < a.xe_lo ? e : a.n_int + e; band = t / nxe; bh = a.band_h_xe;
-    }
-    const int x0 = strip * C::CW;
-    const int yb = a.band_base + band * bh;
-    const int lo = max(yb, a.row0), hi = min(yb + bh, a.row1);
-    const int ybase = yb + r;
-    const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
-    const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;      // exclusive
-    if (jlo >= jhi) return;
-    const bool xedge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W);
-#ifdef RMD_ATROUS_TRACE
-    const unsigned long long trace_t0 = wall_clock64(), trace_c0 = __builtin_amdgcn_s_memtime();
-#endif
-    if (xedge) atrous_pair_body<S, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
-    else       atrous_pair_body<S, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
-#ifdef RMD_ATROUS_TRACE
-    __syncthreads();
-    if (tid == 0 && pid < 8192) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_atrous_trace[6 * pid + 0] = trace_t0;
-        g_atrous_trace[6 * pid + 1] = wall_clock64();
-        g_atrous_trace[6 * pid + 2] = ((unsigned long long)xcc << 32) | hw;
-        g_atrous_trace[6 * pid + 3] = ((unsigned long long)L << 8) | (xedge ? 1u : 0u);
-        g_atrous_trace[6 * pid + 4] = __builtin_amdgcn_s_memtime() - trace_c0;
-        g_atrous_trace[6 * pid + 5] = (unsigned long long)(jhi - jlo);
-    }
-#endif
-}
-
-// ------------------------------------------------------------------------- 2 x 2 pixel block per lane (variant 8)
-// The pixel-pair arithmetic with TWO output rows per wave: a lane owns pixels (xA, xA+1) of lattice rows jw and
-// jw+1, walks the 5 x 6 tap positions both rows see and weighs each position for the rows that tap it (rows 1..4
-// of the window for both, row 0 for the upper and row 5 for the lower output only).  One position is four
-// ds_read_b128 as before, so an output costs 480 instead of 800 bytes of LDS reads with every instruction still
-// packed (the row-pair kernel has the same LDS ratio but weighs its rows 0 and 5 unpacked).  A step yields 8
-// lattice rows from a ring of 12; that is 59-70 KB of LDS, i.e. two workgroups = 2 waves per SIMD with up to
-// 256 VGPRs each, which the two independent accumulator sets and the refill registers (12 + 16 loads in flight
-// per lane) use.  Same per-output operation order as atrous_direct2_kernel: identical bits.
-template <int S>
-struct QuadCfg {
-    using P = PairCfg<S>;
-    static constexpr int ADV = 8, NR = 12;           // ring rows j-2 .. j+9; a step yields rows j .. j+7 (two per wave)
-    static constexpr int RING_BYTES = NR * P::ROW_BYTES;
-    static constexpr int AUX_OFF = RING_BYTES;       // per output row of the step: var(y-1), var(y+1)
-    static constexpr int LDS_BYTES = AUX_OFF + ADV * 2 * P::AUX_ROW;
-    static constexpr int WG_PER_CU = 2 * LDS_BYTES <= 160 * 1024 ? 2 : 1;
-};
-
-template <int S, bool XE>
-__device__ __forceinline__ void atrous_quad_body(const AtrousArgs& a, unsigned char* lds, const int tid,
-                                                 const int x0, const int ybase, const int jlo, const int jhi)
-{
-    using C = PairCfg<S>;
-    using Q = QuadCfg<S>;
-    const Geom g = a.g;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave -> output rows j + 2 wv, j + 2 wv + 1 of the step
-    const int xA = x0 + 2 * lane;
-    const bool inA = !XE || xA < g.W, inB = !XE || xA + 1 < g.W;
-    const float* in_f = reinterpret_cast<const float*>(a.in);
-    const float* nd_f = reinterpret_cast<const float*>(a.nd);
-    const int blo = max(g.buf_row0, 0), bhi = min(g.buf_row0 + g.buf_rows, g.H);
-
-    auto slot_of = [&](const int j) { return (j + 4 * Q::NR) % Q::NR; };        // j >= -2
-
-    // ---- staging (as in the pixel-pair kernel; a wave stages the two rows jb + 2 wv, jb + 2 wv + 1 of a refill)
-    int gofs[3], sofs[3];
-    float keepx[3];
-    bool sact[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const int col = lane + 64 * q;
-        sact[q] = col < C::PW;
-        const int colc = min(col, C::PW - 1);
-        const int gx = x0 - 2 * S + colc;
-        keepx[q] = (!XE || (gx >= 0 && gx < g.W)) ? 1.0f : 0.0f;
-        gofs[q] = XE ? min(max(gx, 0), g.W - 1) : gx;
-        sofs[q] = (colc >> 1) * 16 + (colc & 1) * 4;
-    }
-    float4 pc[2][3], pn[2][3];
-    bool prow_ok[2] = { true, true };
-    const float4 *prc[2] = { a.in, a.in }, *prn[2] = { a.nd, a.nd };
-    auto begin_rows = [&](const int jb) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int y = ybase + (jb + 2 * wv + r) * S;
-            prow_ok[r] = y >= blo && y < bhi;
-            const int yc = min(max(y, blo), bhi - 1);
-            prc[r] = a.in + (size_t)(yc - g.buf_row0) * (size_t)g.W;
-            prn[r] = a.nd + (size_t)(yc - g.buf_row0) * (size_t)g.W;
-        }
-    };
-    auto load_rows_piece = [&](const int i) {      // i = 0..11: one vector-memory instruction each
-        const int r = i / 6, ii = i % 6;
-        if (ii & 1) pn[r][ii >> 1] = prn[r][gofs[ii >> 1]]; else pc[r][ii >> 1] = prc[r][gofs[ii >> 1]];
-    };
-    auto store_rows = [&](const int jb) {
-        constexpr int PF = C::PLANE / 4;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            unsigned char* row = lds + slot_of(jb + 2 * wv + r) * C::ROW_BYTES;
-            const float krow = prow_ok[r] ? 1.0f : 0.0f;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (sact[q]) {
-                    float* p = reinterpret_cast<float*>(row + sofs[q]);
-                    float nx = pn[r][q].x, ny = pn[r][q].y, nz = pn[r][q].z;
-                    if (XE || !prow_ok[r]) { const float kk = XE ? krow * keepx[q] : krow; nx *= kk; ny *= kk; nz *= kk; }
-                    p[0 * PF] = lum3(pc[r][q].x, pc[r][q].y, pc[r][q].z); p[0 * PF + 2] = pc[r][q].x;
-                    p[1 * PF] = pc[r][q].y;                                p[1 * PF + 2] = pc[r][q].w;
-                    p[2 * PF] = nx;                                        p[2 * PF + 2] = ny;
-                    p[3 * PF] = nz;                                        p[3 * PF + 2] = pn[r][q].w;
-                }
-            }
-        }
-    };
-    int aofs[3], zofs[2];
-    {
-        const int g0 = x0 - 2 + lane, g1 = g0 + 64, g2 = x0 + C::CW - 2 + (lane & 3);
-        aofs[0] = (XE ? min(max(g0, 0), g.W - 1) : g0) * 4 + 3;
-        aofs[1] = (XE ? min(max(g1, 0), g.W - 1) : g1) * 4 + 3;
-        aofs[2] = (XE ? min(max(g2, 0), g.W - 1) : g2) * 4 + 3;
-        zofs[0] = (XE ? min(xA, g.W - 1) : xA) * 4 + 3;
-        zofs[1] = (XE ? min(xA + 1, g.W - 1) : xA + 1) * 4 + 3;
-    }
-    float pau[2][2][2], pax[2][2];                 // [output row][...]
-    f2 zd_cur[2] = { f2{ 0.0f, 0.0f }, f2{ 0.0f, 0.0f } }, zd_next[2] = { zd_cur[0], zd_cur[0] };
-    const float *pup[2] = { in_f, in_f }, *pdn[2] = { in_f, in_f }, *pzr[2] = { nd_f, nd_f };
-    auto begin_aux = [&](const int jo) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int y = min(max(ybase + (jo + 2 * wv + r) * S, blo), bhi - 1);
-            const int yu = max(y - 1, blo), yd = min(y + 1, bhi - 1);
-            pup[r] = in_f + (size_t)(yu - g.buf_row0) * (size_t)g.W * 4;
-            pdn[r] = in_f + (size_t)(yd - g.buf_row0) * (size_t)g.W * 4;
-            pzr[r] = nd_f + (size_t)(yd - g.buf_row0) * (size_t)g.W * 4;
-        }
-    };
-    auto load_aux_piece = [&](const int i) {       // i = 0..15: one vector-memory instruction each
-        const int r = i / 8;
-        switch (i % 8) {
-            case 0: pau[r][0][0] = pup[r][aofs[0]]; break;
-            case 1: pau[r][1][0] = pup[r][aofs[1]]; break;
-            case 2: pax[r][0] = pup[r][aofs[2]]; break;
-            case 3: pau[r][0][1] = pdn[r][aofs[0]]; break;
-            case 4: pau[r][1][1] = pdn[r][aofs[1]]; break;
-            case 5: pax[r][1] = pdn[r][aofs[2]]; break;
-            case 6: zd_next[r].x = pzr[r][zofs[0]]; break;
-            default: zd_next[r].y = pzr[r][zofs[1]]; break;
-        }
-    };
-    auto store_aux = [&]() {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            float* ax = reinterpret_cast<float*>(lds + Q::AUX_OFF + (2 * wv + r) * 2 * C::AUX_ROW);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                ax[k * C::AUXW + lane] = pau[r][0][k];
-                ax[k * C::AUXW + 64 + lane] = pau[r][1][k];
-                if (lane < 4) ax[k * C::AUXW + C::CW + lane] = pax[r][k];
-            }
-            zd_cur[r] = zd_next[r];
-        }
-    };
-
-    float4 out[2][2];                              // [output row][pixel]
-    auto compute = [&](const int j) {
-        const int jw = j + 2 * wv;                 // upper output row; the lower one is jw + 1
-        const int y0 = ybase + jw * S;
-        begin_rows(j + 10);
-        begin_aux(j + Q::ADV);
-        int rb[6];                                 // window rows jw-2 .. jw+3
-#pragma unroll
-        for (int tr = 0; tr < 6; ++tr) rb[tr] = slot_of(jw - 2 + tr) * C::ROW_BYTES + (S + lane) * 16;
-        CenterT<f2> k[2];
-        bool zero[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int cb = rb[2 + r];
-            const int y = y0 + r * S;
-            const f2 cv = lds_f2(lds, cb + 1 * C::PLANE + 8);
-            { const TwoPairs q = lds_quad_at(lds, cb + 2 * C::PLANE); k[r].nx = q.a; k[r].ny = q.b; }
-            { const TwoPairs q = lds_quad_at(lds, cb + 3 * C::PLANE); k[r].nz = q.a; k[r].z = q.b; }
-            k[r].l = lds_f2(lds, cb + 0 * C::PLANE);
-            const bool zA = k[r].nx.x == 0.0f && k[r].ny.x == 0.0f && k[r].nz.x == 0.0f;
-            const bool zB = k[r].nx.y == 0.0f && k[r].ny.y == 0.0f && k[r].nz.y == 0.0f;
-            k[r].zc = f2{ zA ? 1.0f : 0.0f, zB ? 1.0f : 0.0f };
-            zero[r] = (zA && inA) || (zB && inB);
-            const unsigned char* axb = lds + Q::AUX_OFF + (2 * wv + r) * 2 * C::AUX_ROW + lane * 8;
-            const f2 vu_l = lds_f2u(axb, 0 * C::AUX_ROW + 4), vu_c = lds_f2(axb, 0 * C::AUX_ROW + 8), vu_r = lds_f2u(axb, 0 * C::AUX_ROW + 12);
-            const f2 vd_l = lds_f2u(axb, 1 * C::AUX_ROW + 4), vd_c = lds_f2(axb, 1 * C::AUX_ROW + 8), vd_r = lds_f2u(axb, 1 * C::AUX_ROW + 12);
-            const f2 vm_l = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 - 12), vm_r = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 + 4);
-            f2 zr = lds_odd_pair(lds, cb + 3 * C::PLANE + 8 + 4);
-            const f2 zd = zd_cur[r];
-            const bool oku = y - 1 >= 0, okd = y + 1 < g.H;
-            f2 var_c;
-            if (!XE && oku && okd) {
-                f2 v = splat(0.0625f, f2{}) * vu_l;
-                v = fma_(splat(0.125f, f2{}), vm_l, v);  v = fma_(splat(0.0625f, f2{}), vd_l, v);
-                v = fma_(splat(0.125f, f2{}), vu_c, v);  v = fma_(splat(0.25f, f2{}), cv, v);   v = fma_(splat(0.125f, f2{}), vd_c, v);
-                v = fma_(splat(0.0625f, f2{}), vu_r, v); v = fma_(splat(0.125f, f2{}), vm_r, v); v = fma_(splat(0.0625f, f2{}), vd_r, v);
-                var_c = v;
-            } else {
-                float vcs[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int x = xA + i;
-                    const bool okl = !XE || x - 1 >= 0, okr = !XE || x + 1 < g.W;
-                    const float ul = i ? vu_l.y : vu_l.x, uc = i ? vu_c.y : vu_c.x, ur = i ? vu_r.y : vu_r.x;
-                    const float dl = i ? vd_l.y : vd_l.x, dc = i ? vd_c.y : vd_c.x, dr = i ? vd_r.y : vd_r.x;
-                    const float ml = i ? vm_l.y : vm_l.x, mr = i ? vm_r.y : vm_r.x, mc = i ? cv.y : cv.x;
-                    if (okl && okr && oku && okd) { vcs[i] = prefilter9(ul, ml, dl, uc, mc, dc, ur, mr, dr); continue; }
-                    float gs = 0.25f, vs = 0.25f * mc;
-                    if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, ul, vs); }
-                    if (okl)        { gs += 0.125f;  vs = fma_(0.125f, ml, vs); }
-                    if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, dl, vs); }
-                    if (oku)        { gs += 0.125f;  vs = fma_(0.125f, uc, vs); }
-                    if (okd)        { gs += 0.125f;  vs = fma_(0.125f, dc, vs); }
-                    if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, ur, vs); }
-                    if (okr)        { gs += 0.125f;  vs = fma_(0.125f, mr, vs); }
-                    if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, dr, vs); }
-                    vcs[i] = vs / gs;
-                }
-                var_c = f2{ vcs[0], vcs[1] };
-            }
-            if (XE) {
-                if (xA + 1 >= g.W) zr.x = k[r].z.x;
-                if (xA + 2 >= g.W) zr.y = k[r].z.y;
-            }
-            const f2 gz = f2{ fabsf(zr.x - k[r].z.x) + fabsf(zd.x - k[r].z.x), fabsf(zr.y - k[r].z.y) + fabsf(zd.y - k[r].z.y) };
-            center_consts<f2>(k[r], var_c, gz, a.sigma_z, a.sigma_l, (float)S);
-        }
-        bool rowv[6];
-#pragma unroll
-        for (int tr = 0; tr < 6; ++tr) {
-            const int yy = y0 + (tr - 2) * S;
-            rowv[tr] = yy >= 0 && yy < g.H;
-        }
-        const bool any_zero = __builtin_amdgcn_ballot_w64(zero[0] || zero[1]) != 0ull;
-        float sn = a.sigma_n;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));
-        const f2 sn2 = splat(sn, f2{});
-        AccT<f2> acc[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) acc[r] = AccT<f2>{ f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
-
-        auto load_pos = [&](const int pi, TapT<f2>& t) {          // position = (column offset, window row)
-            const int dxi = pi / 6, tr = pi % 6;
-            const int sdx = (dxi - 2) * S;
-            if ((sdx & 1) == 0) {
-                const int off = rb[tr] + (sdx / 2) * 16;
-                { const TwoPairs q = lds_quad_at(lds, off + 0 * C::PLANE); t.l = q.a; t.r = q.b; }
-                { const TwoPairs q = lds_quad_at(lds, off + 1 * C::PLANE); t.g = q.a; t.v = q.b; }
-                { const TwoPairs q = lds_quad_at(lds, off + 2 * C::PLANE); t.nx = q.a; t.ny = q.b; }
-                { const TwoPairs q = lds_quad_at(lds, off + 3 * C::PLANE); t.nz = q.a; t.z = q.b; }
-            } else {
-                const int off = rb[tr] + ((sdx - 1) / 2) * 16 + 4;
-                t.l = lds_odd_pair(lds, off + 0 * C::PLANE);  t.r = lds_odd_pair(lds, off + 0 * C::PLANE + 8);
-                t.g = lds_odd_pair(lds, off + 1 * C::PLANE);  t.v = lds_odd_pair(lds, off + 1 * C::PLANE + 8);
-                t.nx = lds_odd_pair(lds, off + 2 * C::PLANE); t.ny = lds_odd_pair(lds, off + 2 * C::PLANE + 8);
-                t.nz = lds_odd_pair(lds, off + 3 * C::PLANE); t.z = lds_odd_pair(lds, off + 3 * C::PLANE + 8);
-            }
-        };
-        auto taps = [&](auto zero_aware) {
-            constexpr bool ZA = decltype(zero_aware)::value;
-            auto weigh = [&](const int pi, const TapT<f2>& t) {
-                const int dx = pi / 6 - 2, tr = pi % 6;
-                const int adx = dx < 0 ? -dx : dx;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const int dy = tr - 2 - r;
-                    if (dy < -2 || dy > 2) continue;
-                    const int ady = dy < 0 ? -dy : dy;
-                    if (dx == 0 && dy == 0) { tap_center<f2>(acc[r], t.l, t.r, t.g, t.v); continue; }
-                    f2 e0 = splat(kLogB3[adx] + kLogB3[ady], f2{});
-                    if (ZA) {
-                        bool okA = rowv[tr], okB = okA;
-                        if (XE) {
-                            okA = okA && xA + dx * S >= 0 && xA + dx * S < g.W;
-                            okB = okB && xA + 1 + dx * S >= 0 && xA + 1 + dx * S < g.W;
-                        }
-                        e0 = f2{ okA ? e0.x : kNegInf, okB ? e0.y : kNegInf };
-                    }
-                    tap_eval<f2, ZA>(acc[r], k[r], t, e0, len_class(adx, ady), sn2);
-                }
-            };
-            // 30 positions, dx outer / window row inner (each output sees its 25 taps in dx-outer / dy-inner order),
-            // double-buffered; the 28 vector-memory instructions of the next refill go out one per position
-            TapT<f2> t0, t1;
-            load_pos(0, t0);
-#pragma unroll
-            for (int q = 0; q < 30; ++q) {
-                if (q < 29) { if (q & 1) load_pos(q + 1, t0); else load_pos(q + 1, t1); }
-                if (q < 12) load_rows_piece(q); else if (q < 28) load_aux_piece(q - 12);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q & 1) weigh(q, t1); else weigh(q, t0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int cb = rb[2 + r];
-            const TwoPairs flr = lds_quad_at(lds, cb + 0 * C::PLANE), fgv = lds_quad_at(lds, cb + 1 * C::PLANE);
-            out[r][0] = finish2(acc[r].sw.x, acc[r].sl.x, acc[r].sr.x, acc[r].sg.x, acc[r].sv.x, flr.a.x, flr.b.x, fgv.a.x, fgv.b.x);
-            out[r][1] = finish2(acc[r].sw.y, acc[r].sl.y, acc[r].sr.y, acc[r].sg.y, acc[r].sv.y, flr.a.y, flr.b.y, fgv.a.y, fgv.b.y);
-        }
-    };
-    auto write_out = [&](const int j) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int jw = j + 2 * wv + r;
-            if (jw >= jlo && jw < jhi) {
-                float4* o = a.out + (size_t)(ybase + jw * S - g.buf_row0) * (size_t)g.W + (size_t)xA;
-                if (inA) o[0] = out[r][0];
-                if (inB) o[1] = out[r][1];
-            }
-        }
-    };
-
-    // ---- prologue: ring rows j0-2 .. j0+9 (one and a half refills) and the aux rows of the first step
-    const int j0 = jlo & ~7;
-    begin_rows(j0 - 2);
-#pragma unroll
-    for (int i = 0; i < 12; ++i) load_rows_piece(i);
-    store_rows(j0 - 2);
-    begin_rows(j0 + 6);                            // rows j0+6 .. j0+13: only j0+6 .. j0+9 (waves 0, 1) belong to the first window
-#pragma unroll
-    for (int i = 0; i < 12; ++i) load_rows_piece(i);
-    begin_aux(j0);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) load_aux_piece(i);
-    if (wv < 2) store_rows(j0 + 6);
-    store_aux();
-    __syncthreads();
-
-    for (int j = j0; j < jhi; j += Q::ADV) {
-        const bool more = j + Q::ADV < jhi;
-        compute(j);
-        if (!more) { write_out(j); break; }
-        __syncthreads();                           // every wave is done reading rows j-2 .. j+5 and the aux rows
-        store_rows(j + 10); store_aux();
-        write_out(j);
-        __syncthreads();
-    }
-}
-
-template <int S>
-__global__ __launch_bounds__(256, 2) void atrous_quad_kernel(AtrousArgs a)
-{
-    using C = PairCfg<S>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char atrous_lds[];
-    const int tid = threadIdx.x;
-    const int pid = blockIdx.x;
-    const int xcd = pid & (kXcds - 1), slot = pid >> 3;
-    int L;
-    if (slot < a.int_per_xcd) { L = xcd * a.int_per_xcd + slot; if (L >= a.total_int) return; }
-    else { L = a.total_int + xcd * a.xe_per_xcd + (slot - a.int_per_xcd); if (L >= a.nblocks) return; }
-    int strip, band, r, bh;
-    if (L < a.total_int) {
-        r = L % S; const int t = L / S;
-        strip = a.xe_lo + t % a.n_int; band = t / a.n_int; bh = a.band_h;
-    } else {
-        const int Lx = L - a.total_int, nxe = a.nstrips - a.n_int;
-        r = Lx % S; const int t = Lx / S, e = t % nxe;
-        strip = e < a.xe_lo ? e : a.n_int + e; band = t / nxe; bh = a.band_h_xe;
-    }
-    const int x0 = strip * C::CW;
-    const int yb = a.band_base + band * bh;
-    const int lo = max(yb, a.row0), hi = min(yb + bh, a.row1);
-    const int ybase = yb + r;
-    const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
-    const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;
-    if (jlo >= jhi) return;
-    const bool xedge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W);
-    if (xedge) atrous_quad_body<S, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
-    else       atrous_quad_body<S, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
-}
-
-// ------------------------------------------------------------------------- loader / consumer form
-// The pixel-pair arithmetic with staging taken out of the compute waves (variant 7).  The ablations of the two
-// kernels above say a step is a chain -- refill loads, 25 x [LDS reads, arithmetic], barrier, LDS stores,
-// barrier -- that overlaps only through the other workgroups of the CU, with the refill one step deep.  Here a
-// workgroup is 4 compute waves + 1 LOADER wave:
-//   loader    streams "packages" k = 0, 1, 2 ... (lattice row j0-2+k of the strip + the variance rows above and
-//             below output row k-4) through a register pipeline three packages deep into the LDS ring, and
-//             publishes a monotonic count of finished packages;
-//   consumers wait for the count to cover the five rows of their output row, compute it (same code path as the
-//             barrier form), store it, and publish how many steps they have finished -- which is what the loader
-//             reads before it overwrites a ring slot.  No workgroup barrier after the prologue.
-// Every spin is bounded: a protocol bug ends in wrong pixels and an error flag, never in a hang.
-#ifndef RMD_LC_DEPTH
-#define RMD_LC_DEPTH 3
-#endif
-template <int S>
-struct LcCfg {
-    using P = PairCfg<S>;
-    // Wave placement decides the shape.  With 128 VGPRs a SIMD holds 4 waves and a workgroup's waves are dealt
-    // round-robin over the SIMDs:
-    //   4 + 1 waves  three workgroups per CU by LDS, but only two became resident (a SIMD would have needed 6 waves)
-    //   6 + 2 waves  two workgroups fill the CU; consumers sit 4 / 4 / 2 / 2 on the SIMDs          <- default
-    //   12 + 4 waves one workgroup per CU, 3 consumers + 1 loader on every SIMD (-DRMD_LC_NC=12 -DRMD_LC_NL=4)
-    // Measured at 4K, steps 2..16: 6+2 150 us, 12+4 170 us per launch -- and 130 us for the 12+4
-    // consumers ALONE (loaders idle, no waits): the arithmetic, not the staging, is what the launch time is made of.
-#ifndef RMD_LC_NC
-#define RMD_LC_NC 6
-#define RMD_LC_NL 2
-#endif
-    static constexpr int NC = RMD_LC_NC, NL = RMD_LC_NL;   // consumer waves (one output row each per step), loader waves
-    static constexpr int THREADS = 64 * (NC + NL);
-    static constexpr int WG_PER_CU = 16 / (NC + NL);
-    static constexpr int NR = NC == 12 ? 22 : 12;           // ring rows: the NC + 4 of a step + spare
-    static constexpr int RING_BYTES = NR * P::ROW_BYTES;
-    static constexpr int AUX_OFF = RING_BYTES;       // var(y-1), var(y+1) per consumer wave (a slot belongs to its wave alone)
-    static constexpr int FLAG_OFF = AUX_OFF + NC * 2 * P::AUX_ROW;
-    static constexpr int LDS_BYTES = FLAG_OFF + 128; // [0..NL) packages committed by loader l, [4..4+NC) steps done by consumer w, [16] error
-    static_assert(NL <= 4 && NC <= 12, "flag layout");
-    static_assert(WG_PER_CU * LDS_BYTES <= 160 * 1024, "LDS of a CU");
-};
-__device__ unsigned int g_atrous_lc_errors;          // protocol time-outs (0 in a correct build): rmd_debug_atrous_protocol_errors
-
-typedef volatile __attribute__((address_space(3))) int lds_flag;
-
-template <int S, bool XE>
-__device__ __forceinline__ void atrous_lc_body(const AtrousArgs& a, unsigned char* lds, const int tid,
-                                               const int x0, const int ybase, const int jlo, const int jhi)
-{
-    using C = PairCfg<S>;
-    using L = LcCfg<S>;
-    const Geom g = a.g;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..NC-1 consumers, then the loaders
-    const int blo = max(g.buf_row0, 0), bhi = min(g.buf_row0 + g.buf_rows, g.H);
-    const int j0 = jlo;
-    const int nsteps = (jhi - j0 + L::NC - 1) / L::NC;
-    const int nrows = L::NC * nsteps;
-    const int npk = nrows + 4;                                     // packages: lattice rows j0-2 .. j0+nrows+1
-    lds_flag* flags = (lds_flag*)(lds + L::FLAG_OFF);
-    constexpr int kSpinLimit = 1 << 22;
-    if (tid < 32) flags[tid] = 0;
-    __syncthreads();
-
-    if (wv >= L::NC) {
-        // =============================================================== loaders: packages k = ld, ld + NL, ...
-        const int ld = wv - L::NC;
-#ifndef RMD_LC_PRIO0
-        __builtin_amdgcn_s_setprio(3);
-#endif
-        const float* in_f = reinterpret_cast<const float*>(a.in);
-        int gofs[3], sofs[3];
-        float keepx[3];
-        bool sact[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int col = lane + 64 * q;
-            sact[q] = col < C::PW;
-            const int colc = min(col, C::PW - 1);
-            const int gx = x0 - 2 * S + colc;
-            keepx[q] = (!XE || (gx >= 0 && gx < g.W)) ? 1.0f : 0.0f;
-            gofs[q] = XE ? min(max(gx, 0), g.W - 1) : gx;
-            sofs[q] = (colc >> 1) * 16 + (colc & 1) * 4;
-        }
-        struct Pkg { float4 c[3], n[3]; };
-        auto issue = [&](const int k, Pkg& p) {                    // 6 vector-memory instructions, unconditional
-            const int y = ybase + (j0 - 2 + k) * S;
-            const int yc = min(max(y, blo), bhi - 1);
-            const float4* rc = a.in + (size_t)(yc - g.buf_row0) * (size_t)g.W;
-            const float4* rn = a.nd + (size_t)(yc - g.buf_row0) * (size_t)g.W;
-#pragma unroll
-#ifdef RMD_LC_ABL_NOLOAD
-            for (int q = 0; q < 3; ++q) { p.c[q] = float4{ (float)k, 1.0f, 2.0f, 0.1f }; p.n[q] = float4{ 0.0f, 0.0f, 1.0f, (float)gofs[q] }; }
-#else
-            for (int q = 0; q < 3; ++q) { p.c[q] = rc[gofs[q]]; p.n[q] = rn[gofs[q]]; }
-#endif
-        };
-        int seen[L::NC] = {};                                      // steps finished by consumer wave w, as last read
-#ifdef RMD_ATROUS_TRACE
-        unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
-#endif
-        auto commit = [&](const int k, const Pkg& p) {
-            RMD_PHASE(7)
-            // The ring slot held package k-NR, whose last reader is output row k-NR.  Output row q is step q/NC of
-            // wave q%NC and a wave finishes its rows in order: wave w must have finished its last row <= k-NR.
-            const int m = k - L::NR;
-            if (m >= 0) {
-                int need[L::NC];
-#pragma unroll
-                for (int w = 0; w < L::NC; ++w) {
-                    const int qw = m - (m - w + L::NC) % L::NC;
-                    need[w] = qw >= 0 ? qw / L::NC + 1 : 0;
-                }
-                auto behind = [&]() {
-                    bool b = false;
-#pragma unroll
-                    for (int w = 0; w < L::NC; ++w) b = b || seen[w] < need[w];
-                    return b;
-                };
-                int spins = 0;
-#ifdef RMD_LC_ABL_NOSYNC
-                if (false)
-#endif
-                while (behind()) {
-#pragma unroll
-                    for (int w = 0; w < L::NC; ++w) seen[w] = __builtin_amdgcn_readfirstlane(flags[4 + w]);
-                    if (!behind()) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > kSpinLimit) { if (lane == 0) { flags[16] = 1; atomicAdd(&g_atrous_lc_errors, 1u); } break; }
-                }
-            }
-            RMD_PHASE(5)
-            const int y = ybase + (j0 - 2 + k) * S;
-            const float krow = (y >= blo && y < bhi) ? 1.0f : 0.0f;
-            unsigned char* row = lds + (k % L::NR) * C::ROW_BYTES;
-            constexpr int PF = C::PLANE / 4;
-#pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                if (sact[q]) {
-                    float* w = reinterpret_cast<float*>(row + sofs[q]);
-                    const float kk = XE ? krow * keepx[q] : krow;
-                    w[0 * PF] = lum3(p.c[q].x, p.c[q].y, p.c[q].z); w[0 * PF + 2] = p.c[q].x;
-                    w[1 * PF] = p.c[q].y;                            w[1 * PF + 2] = p.c[q].w;
-                    w[2 * PF] = p.n[q].x * kk;                       w[2 * PF + 2] = p.n[q].y * kk;
-                    w[3 * PF] = p.n[q].z * kk;                       w[3 * PF + 2] = p.n[q].w;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): the rows are in LDS before the count says so
-            if (lane == 0) flags[ld] = k / L::NL + 1;              // packages this loader has committed
-            RMD_PHASE(6)
-        };
-        constexpr int D = RMD_LC_DEPTH;                            // packages in flight per loader (its registers are the buffer)
-        Pkg p[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) issue(min(ld + L::NL * i, npk - 1), p[i]);
-        for (int k = ld; k < npk; k += L::NL * D) {
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                const int ki = k + L::NL * i;
-                if (ki < npk) commit(ki, p[i]);
-                issue(min(ki + L::NL * D, npk - 1), p[i]);
-            }
-        }
-#ifdef RMD_ATROUS_TRACE
-        if (lane == 0 && blockIdx.x < 8192 && ld == 0)
-            for (int i = 5; i < 8; ++i) g_atrous_phase[8 * blockIdx.x + i] = ph[i];
-#endif
-        return;
-    }
-
-    // ================================================================= consumers
-    const int xA = x0 + 2 * lane;
-    const bool inA = !XE || xA < g.W, inB = !XE || xA + 1 < g.W;
-    const float* nd_f = reinterpret_cast<const float*>(a.nd);
-    int zofs[2];
-    zofs[0] = (XE ? min(xA, g.W - 1) : xA) * 4 + 3;
-    zofs[1] = (XE ? min(xA + 1, g.W - 1) : xA + 1) * 4 + 3;
-    auto load_zd = [&](const int q) {                              // z of row y+1 at the lane's own pixels, output row q
-        const int y = min(max(ybase + (j0 + q) * S, blo), bhi - 1);
-        const float* zr = nd_f + (size_t)(min(y + 1, bhi - 1) - g.buf_row0) * (size_t)g.W * 4;
-        return f2{ zr[zofs[0]], zr[zofs[1]] };
-    };
-    f2 zd_next = load_zd(wv);
-    // variance rows above and below the wave's own output row: slot `wv` of the aux ring belongs to this wave alone
-    const float* in_f = reinterpret_cast<const float*>(a.in);
-    int aofs[3];
-    {
-        const int g0 = x0 - 2 + lane, g1 = g0 + 64, g2 = x0 + C::CW - 2 + (lane & 3);
-        aofs[0] = (XE ? min(max(g0, 0), g.W - 1) : g0) * 4 + 3;
-        aofs[1] = (XE ? min(max(g1, 0), g.W - 1) : g1) * 4 + 3;
-        aofs[2] = (XE ? min(max(g2, 0), g.W - 1) : g2) * 4 + 3;
-    }
-    float au[6];
-    auto load_aux = [&](const int q) {
-        const int yo = min(max(ybase + (j0 + q) * S, blo), bhi - 1);
-        const float* up = in_f + (size_t)(max(yo - 1, blo) - g.buf_row0) * (size_t)g.W * 4;
-        const float* dn = in_f + (size_t)(min(yo + 1, bhi - 1) - g.buf_row0) * (size_t)g.W * 4;
-        au[0] = up[aofs[0]]; au[1] = up[aofs[1]]; au[2] = up[aofs[2]];
-        au[3] = dn[aofs[0]]; au[4] = dn[aofs[1]]; au[5] = dn[aofs[2]];
-    };
-    auto store_aux = [&]() {
-        float* ax = reinterpret_cast<float*>(lds + L::AUX_OFF + wv * 2 * C::AUX_ROW);
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            ax[r * C::AUXW + lane] = au[3 * r + 0];
-            ax[r * C::AUXW + 64 + lane] = au[3 * r + 1];
-            if (lane < 4) ax[r * C::AUXW + C::CW + lane] = au[3 * r + 2];
-        }
-    };
-    load_aux(wv);
-    store_aux();
-    int seen_ready[L::NL] = {};
-#ifdef RMD_ATROUS_TRACE
-    unsigned long long ph[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
-#endif
-    for (int t = 0; t < nsteps; ++t) {
-        const int q = L::NC * t + wv;                              // output row (package numbering: lattice row j0 + q)
-        const int jw = j0 + q;
-        const int y = ybase + jw * S;
-        const f2 zd = zd_next;
-#ifndef RMD_LC_ABL_NOOUT
-        zd_next = load_zd(min(q + L::NC, nrows - 1));
-        load_aux(min(q + L::NC, nrows - 1));
-#endif
-        RMD_PHASE(2)
-        {
-            // main rows q .. q+4 = packages 0 .. q+4: (q + 4 - l) / NL + 1 of them come from loader l
-            int need[L::NL];
-#pragma unroll
-            for (int l = 0; l < L::NL; ++l) need[l] = (q + 4 - l + L::NL) / L::NL;
-            auto behind = [&]() {
-                bool b = false;
-#pragma unroll
-                for (int l = 0; l < L::NL; ++l) b = b || seen_ready[l] < need[l];
-                return b;
-            };
-            int spins = 0;
-#ifdef RMD_LC_ABL_NOSYNC
-            if (false)
-#endif
-            while (behind()) {
-#pragma unroll
-                for (int l = 0; l < L::NL; ++l) seen_ready[l] = __builtin_amdgcn_readfirstlane(flags[l]);
-                if (!behind()) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > kSpinLimit) { if (lane == 0) { flags[16] = 1; atomicAdd(&g_atrous_lc_errors, 1u); } break; }
-            }
-        }
-        RMD_PHASE(0)
-        int rb[5];
-#pragma unroll
-        for (int tr = 0; tr < 5; ++tr) rb[tr] = ((q + tr) % L::NR) * C::ROW_BYTES + (S + lane) * 16;
-        const int cb = rb[2];
-        CenterT<f2> k;
-        const f2 cv = lds_f2(lds, cb + 1 * C::PLANE + 8);
-        { const TwoPairs u = lds_quad_at(lds, cb + 2 * C::PLANE); k.nx = u.a; k.ny = u.b; }
-        { const TwoPairs u = lds_quad_at(lds, cb + 3 * C::PLANE); k.nz = u.a; k.z = u.b; }
-        k.l = lds_f2(lds, cb + 0 * C::PLANE);
-        const bool zA = k.nx.x == 0.0f && k.ny.x == 0.0f && k.nz.x == 0.0f, zB = k.nx.y == 0.0f && k.ny.y == 0.0f && k.nz.y == 0.0f;
-        k.zc = f2{ zA ? 1.0f : 0.0f, zB ? 1.0f : 0.0f };
-        const unsigned char* axb = lds + L::AUX_OFF + wv * 2 * C::AUX_ROW + lane * 8;
-        const f2 vu_l = lds_f2u(axb, 0 * C::AUX_ROW + 4), vu_c = lds_f2(axb, 0 * C::AUX_ROW + 8), vu_r = lds_f2u(axb, 0 * C::AUX_ROW + 12);
-        const f2 vd_l = lds_f2u(axb, 1 * C::AUX_ROW + 4), vd_c = lds_f2(axb, 1 * C::AUX_ROW + 8), vd_r = lds_f2u(axb, 1 * C::AUX_ROW + 12);
-        const f2 vm_l = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 - 12), vm_r = lds_odd_pair(lds, cb + 1 * C::PLANE + 8 + 4);
-        f2 zr = lds_odd_pair(lds, cb + 3 * C::PLANE + 8 + 4);
-        const bool oku = y - 1 >= 0, okd = y + 1 < g.H;
-        // (the six aux reads above have returned before their values are used below; the slot is rewritten at the
-        //  end of the step, in program order of this wave)
-        f2 var_c;
-        if (!XE && oku && okd) {
-            f2 v = splat(0.0625f, f2{}) * vu_l;
-            v = fma_(splat(0.125f, f2{}), vm_l, v);  v = fma_(splat(0.0625f, f2{}), vd_l, v);
-            v = fma_(splat(0.125f, f2{}), vu_c, v);  v = fma_(splat(0.25f, f2{}), cv, v);   v = fma_(splat(0.125f, f2{}), vd_c, v);
-            v = fma_(splat(0.0625f, f2{}), vu_r, v); v = fma_(splat(0.125f, f2{}), vm_r, v); v = fma_(splat(0.0625f, f2{}), vd_r, v);
-            var_c = v;
-        } else {
-            float vcs[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int x = xA + i;
-                const bool okl = !XE || x - 1 >= 0, okr = !XE || x + 1 < g.W;
-                const float ul = i ? vu_l.y : vu_l.x, uc = i ? vu_c.y : vu_c.x, ur = i ? vu_r.y : vu_r.x;
-                const float dl = i ? vd_l.y : vd_l.x, dc = i ? vd_c.y : vd_c.x, dr = i ? vd_r.y : vd_r.x;
-                const float ml = i ? vm_l.y : vm_l.x, mr = i ? vm_r.y : vm_r.x, mc = i ? cv.y : cv.x;
-                if (okl && okr && oku && okd) { vcs[i] = prefilter9(ul, ml, dl, uc, mc, dc, ur, mr, dr); continue; }
-                float gs = 0.25f, vs = 0.25f * mc;
-                if (okl && oku) { gs += 0.0625f; vs = fma_(0.0625f, ul, vs); }
-                if (okl)        { gs += 0.125f;  vs = fma_(0.125f, ml, vs); }
-                if (okl && okd) { gs += 0.0625f; vs = fma_(0.0625f, dl, vs); }
-                if (oku)        { gs += 0.125f;  vs = fma_(0.125f, uc, vs); }
-                if (okd)        { gs += 0.125f;  vs = fma_(0.125f, dc, vs); }
-                if (okr && oku) { gs += 0.0625f; vs = fma_(0.0625f, ur, vs); }
-                if (okr)        { gs += 0.125f;  vs = fma_(0.125f, mr, vs); }
-                if (okr && okd) { gs += 0.0625f; vs = fma_(0.0625f, dr, vs); }
-                vcs[i] = vs / gs;
-            }
-            var_c = f2{ vcs[0], vcs[1] };
-        }
-        if (XE) {
-            if (xA + 1 >= g.W) zr.x = k.z.x;
-            if (xA + 2 >= g.W) zr.y = k.z.y;
-        }
-        const f2 gz = f2{ fabsf(zr.x - k.z.x) + fabsf(zd.x - k.z.x), fabsf(zr.y - k.z.y) + fabsf(zd.y - k.z.y) };
-        center_consts<f2>(k, var_c, gz, a.sigma_z, a.sigma_l, (float)S);
-        bool rowv[5];
-#pragma unroll
-        for (int tr = 0; tr < 5; ++tr) {
-            const int yy = y + (tr - 2) * S;
-            rowv[tr] = yy >= 0 && yy < g.H;
-        }
-        const bool any_zero = __builtin_amdgcn_ballot_w64((zA && inA) || (zB && inB)) != 0ull;
-        float sn = a.sigma_n;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));
-        const f2 sn2 = splat(sn, f2{});
-        AccT<f2> acc = { f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
-        auto load_tap = [&](const int ti, TapT<f2>& tp) {
-#ifdef RMD_LC_ABL_NOLDS
-            // ablation: no LDS reads -- the tap values are register values the compiler cannot see through
-            tp.l = k.l; tp.r = k.nx; tp.g = k.ny; tp.v = k.nz; tp.nx = k.nx; tp.ny = k.ny; tp.nz = k.nz; tp.z = k.z;
-            asm volatile("" : "+v"(tp.l), "+v"(tp.r), "+v"(tp.g), "+v"(tp.v), "+v"(tp.nx), "+v"(tp.ny), "+v"(tp.nz), "+v"(tp.z));
-            return;
-#endif
-            const int dxi = ti / 5, tr = ti % 5;
-            const int sdx = (dxi - 2) * S;
-            if ((sdx & 1) == 0) {
-                const int off = rb[tr] + (sdx / 2) * 16;
-                { const TwoPairs u = lds_quad_at(lds, off + 0 * C::PLANE); tp.l = u.a; tp.r = u.b; }
-                { const TwoPairs u = lds_quad_at(lds, off + 1 * C::PLANE); tp.g = u.a; tp.v = u.b; }
-                { const TwoPairs u = lds_quad_at(lds, off + 2 * C::PLANE); tp.nx = u.a; tp.ny = u.b; }
-                { const TwoPairs u = lds_quad_at(lds, off + 3 * C::PLANE); tp.nz = u.a; tp.z = u.b; }
-            } else {
-                const int off = rb[tr] + ((sdx - 1) / 2) * 16 + 4;
-                tp.l = lds_odd_pair(lds, off + 0 * C::PLANE);  tp.r = lds_odd_pair(lds, off + 0 * C::PLANE + 8);
-                tp.g = lds_odd_pair(lds, off + 1 * C::PLANE);  tp.v = lds_odd_pair(lds, off + 1 * C::PLANE + 8);
-                tp.nx = lds_odd_pair(lds, off + 2 * C::PLANE); tp.ny = lds_odd_pair(lds, off + 2 * C::PLANE + 8);
-                tp.nz = lds_odd_pair(lds, off + 3 * C::PLANE); tp.z = lds_odd_pair(lds, off + 3 * C::PLANE + 8);
-            }
-        };
-        auto taps = [&](auto zero_aware) {
-            constexpr bool ZA = decltype(zero_aware)::value;
-            auto weigh = [&](const int ti, const TapT<f2>& tp) {
-                const int dx = ti / 5 - 2, dy = ti % 5 - 2;
-                const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-                if (dx == 0 && dy == 0) {
-                    const TwoPairs lr = lds_quad_at(lds, cb + 0 * C::PLANE), gv = lds_quad_at(lds, cb + 1 * C::PLANE);
-                    tap_center<f2>(acc, lr.a, lr.b, gv.a, gv.b);
-                    return;
-                }
-                f2 e0 = splat(kLogB3[adx] + kLogB3[ady], f2{});
-                if (ZA) {
-                    bool okA = rowv[dy + 2], okB = okA;
-                    if (XE) {
-                        okA = okA && xA + dx * S >= 0 && xA + dx * S < g.W;
-                        okB = okB && xA + 1 + dx * S >= 0 && xA + 1 + dx * S < g.W;
-                    }
-                    e0 = f2{ okA ? e0.x : kNegInf, okB ? e0.y : kNegInf };
-                }
-                tap_eval<f2, ZA>(acc, k, tp, e0, len_class(adx, ady), sn2);
-            };
-            TapT<f2> t0, t1;
-            load_tap(0, t0);
-#pragma unroll
-            for (int i = 0; i < 24; ++i) {
-                const int ti = i < 12 ? i : i + 1, tn = i + 1 < 12 ? i + 1 : i + 2;
-                if (i == 12) weigh(12, t0);
-                if (i < 23) { if (i & 1) load_tap(tn, t0); else load_tap(tn, t1); }
-                __builtin_amdgcn_sched_barrier(0);
-                if (i & 1) weigh(ti, t1); else weigh(ti, t0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
-        const TwoPairs flr = lds_quad_at(lds, cb + 0 * C::PLANE), fgv = lds_quad_at(lds, cb + 1 * C::PLANE);
-        const float4 outA = finish2(acc.sw.x, acc.sl.x, acc.sr.x, acc.sg.x, acc.sv.x, flr.a.x, flr.b.x, fgv.a.x, fgv.b.x);
-        const float4 outB = finish2(acc.sw.y, acc.sl.y, acc.sr.y, acc.sg.y, acc.sv.y, flr.a.y, flr.b.y, fgv.a.y, fgv.b.y);
-        // every LDS read of this step has returned (its value was used): the slots may be recycled
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        if (lane == 0) flags[4 + wv] = t + 1;
-        RMD_PHASE(1)
-        store_aux();
-#ifdef RMD_LC_ABL_NOOUT
-        if (outA.x + outB.x == -12345.678f)
-#endif
-        if (jw >= jlo && jw < jhi) {
-            float4* o = a.out + (size_t)(y - g.buf_row0) * (size_t)g.W + (size_t)xA;
-            if (inA) o[0] = outA;
-            if (inB) o[1] = outB;
-        }
-        RMD_PHASE(2)
-    }
-#ifdef RMD_ATROUS_TRACE
-    if (lane == 0 && blockIdx.x < 8192 && (wv == 0 || wv == L::NC - 1)) {
-        if (wv == 0) for (int i = 0; i < 3; ++i) g_atrous_phase[8 * blockIdx.x + i] = ph[i];
-        else         for (int i = 0; i < 2; ++i) g_atrous_phase[8 * blockIdx.x + 3 + i] = ph[i];
-    }
-#endif
-}
-
-template <int S>
-__global__ __launch_bounds__(LcCfg<S>::THREADS, 4) void atrous_lc_kernel(AtrousArgs a)
-{
-    using C = PairCfg<S>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char atrous_lds[];
-    const int tid = threadIdx.x;
-    const int pid = blockIdx.x;
-    const int xcd = pid & (kXcds - 1), slot = pid >> 3;
-    int L;
-    if (slot < a.int_per_xcd) { L = xcd * a.int_per_xcd + slot; if (L >= a.total_int) return; }
-    else { L = a.total_int + xcd * a.xe_per_xcd + (slot - a.int_per_xcd); if (L >= a.nblocks) return; }
-    int strip, band, r, bh;
-    if (L < a.total_int) {
-        r = L % S; const int t = L / S;
-        strip = a.xe_lo + t % a.n_int; band = t / a.n_int; bh = a.band_h;
-    } else {
-        const int Lx = L - a.total_int, nxe = a.nstrips - a.n_int;
-        r = Lx % S; const int t = Lx / S, e = t % nxe;
-        strip = e < a.xe_lo ? e : a.n_int + e; band = t / nxe; bh = a.band_h_xe;
-    }
-    const int x0 = strip * C::CW;
-    const int yb = a.band_base + band * bh;
-    const int lo = max(yb, a.row0), hi = min(yb + bh, a.row1);
-    const int ybase = yb + r;
-    const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
-    const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;
-    if (jlo >= jhi) return;
-    const bool xedge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W);
-#ifdef RMD_ATROUS_TRACE
-    const unsigned long long trace_t0 = wall_clock64(), trace_c0 = __builtin_amdgcn_s_memtime();
-#endif
-    if (xedge) atrous_lc_body<S, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
-    else       atrous_lc_body<S, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
-#ifdef RMD_ATROUS_TRACE
-    __syncthreads();
-    if (tid == 0 && pid < 8192) {
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_atrous_trace[6 * pid + 0] = trace_t0;
-        g_atrous_trace[6 * pid + 1] = wall_clock64();
-        g_atrous_trace[6 * pid + 2] = ((unsigned long long)xcc << 32) | hw;
-        g_atrous_trace[6 * pid + 3] = ((unsigned long long)L << 8) | (xedge ? 1u : 0u);
-        g_atrous_trace[6 * pid + 4] = __builtin_amdgcn_s_memtime() - trace_c0;
-        g_atrous_trace[6 * pid + 5] = (unsigned long long)(jhi - jlo);
-    }
-#endif
-}
-
-template <int S, int MODE = 0>                      // 0 pixel-pair (barriers), 1 loader/consumer, 2 quad (2 x 2 block per lane)
-static int launch_pair(AtrousArgs a, hipStream_t stream)
-{
-    using C = PairCfg<S>;
-    constexpr bool LC = MODE == 1, QD = MODE == 2;
-    const void* fn = LC ? reinterpret_cast<const void*>(&atrous_lc_kernel<S>)
-                   : QD ? reinterpret_cast<const void*>(&atrous_quad_kernel<S>) : reinterpret_cast<const void*>(&atrous_pair_kernel<S>);
-    constexpr int lds_bytes = LC ? LcCfg<S>::LDS_BYTES : QD ? QuadCfg<S>::LDS_BYTES : C::LDS_BYTES;
-    if (first_use_on_device(fn))
-        RMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    a.band_base = a.row0 / (8 * S) * (8 * S);
-    const int rows = a.row1 - a.band_base;
-    a.nstrips = (a.g.W + C::CW - 1) / C::CW;
-    // strips whose staged columns leave the frame (same test as the kernel's)
-    int xe_lo = 0, xe_hi = 0;
-    for (int st = 0; st < a.nstrips && st * C::CW - 2 * S < 0; ++st) ++xe_lo;
-    for (int st = a.nstrips - 1; st >= xe_lo && st * C::CW + C::CW + 2 * S > a.g.W; --st) ++xe_hi;
-    a.xe_lo = xe_lo;
-    a.n_int = a.nstrips - xe_lo - xe_hi;
-    const int nxe = xe_lo + xe_hi;
-    // Band count: every workgroup of a launch does the same work (border strips half of it, their body is
-    // slower), so the launch runs in ceil(workgroups / resident slots) rounds; take the band count that
-    // fills the rounds best, discounted by the 4 halo rows a workgroup stages on top of its own rows.
-    // (3840 wide: 28 interior + 2 border strips = 32 S b workgroups, i.e. exactly 768 for S <= 8.)
-    const int unit = S * (LC ? LcCfg<S>::NC : QD ? QuadCfg<S>::ADV : C::ADV);
-    const int slots = (LC ? LcCfg<S>::WG_PER_CU : QD ? QuadCfg<S>::WG_PER_CU : C::WG_PER_CU) * a.cus;
-    int best_nb = 1;
-    double best = -1.0;
-    for (int nb = 1; nb <= 64; ++nb) {
-        int h = (rows + nb - 1) / nb;
-        h = ((h + unit - 1) / unit) * unit;
-        const int bands = (rows + h - 1) / h;
-        int hx = ((h / 2 + unit - 1) / unit) * unit;
-        const int bands_x = (rows + hx - 1) / hx;
-        const int wgs = (a.n_int * bands + nxe * bands_x) * S;
-        const int rounds = (wgs + slots - 1) / slots;
-        const double lattice_rows = (double)h / S;
-        const double eff = (double)wgs / ((double)rounds * slots) * lattice_rows / (lattice_rows + 4.0);
-        if (eff > best + 1e-9) { best = eff; best_nb = nb; }
-        if (h == unit) break;
-    }
-    int h = (rows + best_nb - 1) / best_nb;
-    h = ((h + unit - 1) / unit) * unit;
-    a.band_h = h;
-    a.band_h_xe = ((h / 2 + unit - 1) / unit) * unit;
-    const int nbands = (rows + h - 1) / h, nbands_x = (rows + a.band_h_xe - 1) / a.band_h_xe;
-    a.total_int = a.n_int * nbands * S;
-    a.nblocks = a.total_int + nxe * nbands_x * S;
-    a.int_per_xcd = (a.total_int + kXcds - 1) / kXcds;
-    a.xe_per_xcd = (a.nblocks - a.total_int + kXcds - 1) / kXcds;
-    a.per_xcd = a.int_per_xcd + a.xe_per_xcd;
-    if (LC)      hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_lc_kernel<S>), dim3(a.per_xcd * kXcds), dim3(LcCfg<S>::THREADS), lds_bytes, stream, a);
-    else if (QD) hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_quad_kernel<S>), dim3(a.per_xcd * kXcds), dim3(256), lds_bytes, stream, a);
-    else         hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_pair_kernel<S>), dim3(a.per_xcd * kXcds), dim3(256), lds_bytes, stream, a);
-    RMD_LAUNCH_CHECK("atrous_pair_kernel");
-    return RMD_OK;
-}
-
-static int launch_lc_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
-{
-    switch (iteration) {
-        case 0: return launch_pair<1, 1>(a, stream);
-        case 1: return launch_pair<2, 1>(a, stream);
-        case 2: return launch_pair<4, 1>(a, stream);
-        case 3: return launch_pair<8, 1>(a, stream);
-        default: return launch_pair<16, 1>(a, stream);
-    }
-}
-
-static int launch_quad_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
-{
-    switch (iteration) {
-        case 0: return launch_pair<1, 2>(a, stream);
-        case 1: return launch_pair<2, 2>(a, stream);
-        case 2: return launch_pair<4, 2>(a, stream);
-        case 3: return launch_pair<8, 2>(a, stream);
-        default: return launch_pair<16, 2>(a, stream);
-    }
-}
-
-static int launch_pair_iter(int iteration, const AtrousArgs& a, hipStream_t stream)
-{
-    switch (iteration) {
-        case 0: return launch_pair<1>(a, stream);
-        case 1: return launch_pair<2>(a, stream);
-        case 2: return launch_pair<4>(a, stream);
-        case 3: return launch_pair<8>(a, stream);
-        default: return launch_pair<16>(a, stream);
-    }
-}
 
 // Work decomposition of one stream launch: fills the band fields of `a`, returns the efficiency estimate
 // (share of the resident workgroup slots used by whole rounds) x (own lattice rows / staged lattice rows).
@@ -2316,7 +841,7 @@ static double plan_stream(AtrousArgs& a)
     // Candidates: nb bands for every strip, or nb + 1 for x of the strips, x as large as the rounds nb needs
     // anyway leave room for (3840 wide, step 2: 30 strips x 2 lattices x 12 bands = 720 workgroups for 768 slots
     // left 48 CUs with two workgroups instead of three; 24 strips with 13 bands make it 768).
-    static const int mixed = [] { const char* e = getenv("RMD_ATROUS_MIXED_BANDS"); return e ? atoi(e) : 1; }();
+    static const int mixed = tuning_env("RMD_ATROUS_MIXED_BANDS", 1);
     auto round_up = [&](int h) { return ((h + unit - 1) / unit) * unit; };
     int best_h = round_up(rows), best_hh = best_h, best_x = 0;
     double best = -1.0;
@@ -2379,13 +904,10 @@ static int launch_stream(AtrousArgs a, hipStream_t stream)
 // measured against it with bench.py's timing and never won: four row pairs on 64-column strips (NP = 4: 127 /
 // 132 / 131 / 139 / 142 us per 4K iteration against 125 / 131 / 132 / 133 / 140) and one row pair on 256-column
 // strips (NP = 1, two workgroups per CU: 84 us per iteration on a 7680x540 strip against 74-80, and 84.5 against
-// 86.4 only at step 16, where NP = 2 has 960 workgroups for 768 slots).  RMD_ATROUS_NP = 1 | 4 forces them.
+// 86.4 only at step 16, where NP = 2 has 960 workgroups for 768 slots).  atrous_variant 2 / 6 of the experiments build run them.
 template <int S>
 static int launch_stream_auto(AtrousArgs a, hipStream_t stream)
 {
-    static const int force = [] { const char* e = getenv("RMD_ATROUS_NP"); return e ? atoi(e) : 0; }();
-    if (force == 1) return launch_stream<S, 1>(a, stream);
-    if (force == 4 && S <= 8) return launch_stream<S, 4>(a, stream);
     return launch_stream<S, 2>(a, stream);
 }
 
@@ -2441,7 +963,11 @@ extern "C" int rmd_debug_atrous_plan(int width, int height, int row0, int row1, 
 extern "C" int rmd_debug_atrous_protocol_errors(unsigned int* count)
 {
     if (!count) return fail(RMD_E_NULL, "rmd_debug_atrous_protocol_errors: count is NULL");
+#ifdef RMD_EXPERIMENTS
     RMD_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_atrous_lc_errors), sizeof(unsigned int)));
+#else
+    *count = 0;     // variant 7 (the only kernel with a counter protocol) is not in this build
+#endif
     return RMD_OK;
 }
 
@@ -2478,32 +1004,31 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
         if (iteration <= 4) return launch_stream_auto_iter(iteration, a, as_stream(stream));
         variant = 1;
     }
-    if ((variant == 2 || variant == 3) && iteration > 4)
-        return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
-    if (variant == 4) {
+    if (variant == 3) {                                                               // 128 columns x 2 row pairs (= the default for iterations 0..4)
         if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
-        return launch_pair_iter(iteration, a, as_stream(stream));                       // pixel pairs, SoA LDS planes
+        return launch_stream_iter<2>(iteration, a, as_stream(stream));
     }
-    if (variant == 7) {
+    if (variant == 2 || (variant >= 4 && variant <= 8)) {
+#ifdef RMD_EXPERIMENTS
+        // formulations that were measured and lost (DESIGN.md sections 4.4-4.7); experiments build only
         if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
-        return launch_lc_iter(iteration, a, as_stream(stream));                         // pixel pairs, loader wave + 4 compute waves
+        switch (variant) {
+            case 2: return launch_stream_iter<1>(iteration, a, as_stream(stream));     // 256 columns x 1 row pair
+            case 6: return launch_stream_iter<4>(iteration, a, as_stream(stream));     // 64 columns x 4 row pairs
+            case 4: return launch_pair_iter(iteration, a, as_stream(stream));          // pixel pairs, SoA LDS planes
+            case 7: return launch_lc_iter(iteration, a, as_stream(stream));            // pixel pairs, loader waves + compute waves
+            case 8: return launch_quad_iter(iteration, a, as_stream(stream));          // 2 x 2 pixel block per lane
+            default: {
+                dim3 grid5((f->width + 63) / 64, (row1 - row0 + 3) / 4);
+                hipLaunchKernelGGL(atrous_direct2_kernel, grid5, dim3(256), 0, as_stream(stream), a);
+                RMD_LAUNCH_CHECK("atrous_direct2_kernel");
+                return RMD_OK;
+            }
+        }
+#else
+        return fail(RMD_E_UNSUPPORTED, "rmd_svgf_atrous: atrous_variant %d is an experiment (make experiments; rmd_has_experiments() == 0 here)", variant);
+#endif
     }
-    if (variant == 8) {
-        if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
-        return launch_quad_iter(iteration, a, as_stream(stream));                       // 2 x 2 pixel block per lane
-    }
-    if (variant == 5) {
-        dim3 grid5((f->width + 63) / 64, (row1 - row0 + 3) / 4);
-        hipLaunchKernelGGL(atrous_direct2_kernel, grid5, dim3(256), 0, as_stream(stream), a);
-        RMD_LAUNCH_CHECK("atrous_direct2_kernel");
-        return RMD_OK;
-    }
-    if (variant == 6) {                                                               // 64 columns x 4 row pairs
-        if (iteration > 4) return fail(RMD_E_PARAM, "rmd_svgf_atrous: the stream variants cover iterations 0..4");
-        return launch_stream_iter<4>(iteration, a, as_stream(stream));
-    }
-    if (variant == 2) return launch_stream_iter<1>(iteration, a, as_stream(stream));   // 256 columns x 1 row pair
-    if (variant == 3) return launch_stream_iter<2>(iteration, a, as_stream(stream));   // 128 columns x 2 row pairs
     if (variant != 1) return fail(RMD_E_PARAM, "rmd_svgf_atrous: unknown atrous_variant %d", p->atrous_variant);
     dim3 grid((f->width + 63) / 64, (row1 - row0 + 3) / 4);
     hipLaunchKernelGGL(atrous_direct_kernel, grid, dim3(256), 0, as_stream(stream), a);

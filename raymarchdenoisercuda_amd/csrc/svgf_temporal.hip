@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     temporal_tile(a, blockIdx.x, a.row0 / 4 + blockIdx.y);
 }
 
+#ifdef RMD_EXPERIMENTS
 // A fixed, small number of workgroups (one per CU) that walk over the tiles: the form that runs
 // UNDERNEATH the a-trous launches of the previous frame (rmd_svgf_params.tv_workgroups).  Three
 // a-trous workgroups leave 56 VGPRs per SIMD; one wave of this kernel fits there.  A grid of one
@@ -168,12 +169,14 @@ __global__ __launch_bounds__(256) void svgf_temporal_persistent_kernel(TemporalA
     const int ntiles = a.tiles_x * tiles_y;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) temporal_tile(a, t % a.tiles_x, a.row0 / 4 + t / a.tiles_x);
 }
+#endif
 
 }  // namespace rmd
 
 using namespace rmd;
 
-int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused)
+int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused,
+                         bool sparse_t_color)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_temporal: params is NULL");
@@ -202,7 +205,7 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.prev_nd = (const float4*)f->prev_nd;
     a.t_color = (float4*)f->t_color; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
     a.v_color = nullptr;
-    a.sparse_t_color = rmd::variance_reads_sparse_t_color(f, p, fused) ? 1 : 0;
+    a.sparse_t_color = (fused && sparse_t_color) ? 1 : 0;
     a.tile_flags = nullptr; a.tiles_x = (f->width + 63) / 64; a.var_h_threshold = p->var_h_threshold;
     if (fused) {
         a.tile_flags = f->v_tile_flags;
@@ -215,7 +218,11 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
     dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
     if (p->tv_workgroups > 0) {
+#ifdef RMD_EXPERIMENTS
         hipLaunchKernelGGL(svgf_temporal_persistent_kernel, dim3(p->tv_workgroups), dim3(256), 0, as_stream(stream), a, (int)grid.y);
+#else
+        return fail(RMD_E_UNSUPPORTED, "rmd_svgf_temporal: tv_workgroups > 0 (persistent T / V grids) is an experiment (make experiments)");
+#endif
     } else {
         hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
     }
@@ -225,5 +232,5 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
 
 extern "C" int rmd_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
 {
-    return rmd::launch_temporal(f, p, row0, row1, stream, /*fused=*/false);
+    return rmd::launch_temporal(f, p, row0, row1, stream, /*fused=*/false, /*sparse_t_color=*/false);
 }

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(256) void svgf_variance_tile_kernel(VarianceArgs a,
     }
 }
 
+#ifdef RMD_EXPERIMENTS
 // Fused frames only (tile flags from T, no statistics): a fixed number of workgroups, each looking
 // at the flags of every gridDim.x-th tile (64 per coalesced-by-stride load and ballot) and running
 // the flagged ones.  Constant footprint, for the same reason as svgf_temporal_persistent_kernel; the
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256) void svgf_variance_persistent_kernel(VarianceA
         }
     }
 }
+#endif
 
 }  // namespace rmd
 
@@ -288,17 +290,21 @@ using namespace rmd;
 
 static int env_v_workgroups()
 {
-    static const int v = [] { const char* e = getenv("RMD_V_WORKGROUPS"); return e ? atoi(e) : -1; }();
+    static const int v = tuning_env("RMD_V_WORKGROUPS", -1);
     return v;
 }
 
+// true when a fused frame's V pass will be svgf_variance_tile_kernel, the one form that can take the unflagged pixels of
+// its windows from v_color: rmd_svgf_frame_tv evaluates this ONCE and hands the answer to both launchers, so T (which
+// then writes t_color only inside flagged tiles) and V cannot disagree about it
 bool rmd::variance_reads_sparse_t_color(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, bool fused)
 {
-    static const int sparse = [] { const char* e = getenv("RMD_SPARSE_T_COLOR"); return e ? atoi(e) : 1; }();
+    static const int sparse = tuning_env("RMD_SPARSE_T_COLOR", 1);
     return sparse && fused && !f->stats && f->v_tile_flags && p->var_radius == kVR && p->tv_workgroups == 0 && env_v_workgroups() < 0;
 }
 
-int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused)
+int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused,
+                         bool sparse_t_color)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_variance: params is NULL");
@@ -326,12 +332,20 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
     if (p->tv_workgroups < 0 || p->tv_workgroups > 65536) return fail(RMD_E_PARAM, "rmd_svgf_variance: tv_workgroups %d outside [0,65536]", p->tv_workgroups);
     const int v_wgs = p->tv_workgroups > 0 ? p->tv_workgroups : env_v_workgroups();
-    a.sparse_t_color = variance_reads_sparse_t_color(f, p, fused) ? 1 : 0;
+    a.sparse_t_color = sparse_t_color ? 1 : 0;
+    const bool tile_form = a.tile_flags && a.radius == kVR && v_wgs < 0;
+    // T wrote t_color only inside the tiles it flagged: every other form of V would read stale pixels
+    if (sparse_t_color && !tile_form)
+        return fail(RMD_E_PARAM, "rmd_svgf_variance: sparse t_color needs the tile form of V (fused frame, tile flags, var_radius %d, no statistics)", kVR);
     if (a.tile_flags && v_wgs > 0) {
+#ifdef RMD_EXPERIMENTS
         const dim3 pg(v_wgs);
         if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_persistent_kernel<3>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
         else               hipLaunchKernelGGL(svgf_variance_persistent_kernel<0>, pg, dim3(256), 0, as_stream(stream), a, (int)grid.y);
-    } else if (a.tile_flags && a.radius == kVR && v_wgs != 0) {
+#else
+        return fail(RMD_E_UNSUPPORTED, "rmd_svgf_variance: tv_workgroups > 0 (persistent T / V grids) is an experiment (make experiments)");
+#endif
+    } else if (tile_form) {
         hipLaunchKernelGGL(svgf_variance_tile_kernel, dim3(kVGrid), dim3(256), 0, as_stream(stream), a, (int)grid.y);
     } else {
         if (a.radius == 3) hipLaunchKernelGGL(svgf_variance_kernel<3>, grid, dim3(256), 0, as_stream(stream), a);
@@ -343,5 +357,5 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
 
 extern "C" int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
 {
-    return rmd::launch_variance(f, p, row0, row1, stream, /*fused=*/false);
+    return rmd::launch_variance(f, p, row0, row1, stream, /*fused=*/false, /*sparse_t_color=*/false);
 }

@@ -39,9 +39,11 @@ void CudaGBuffer::openImages(std::string filepath, void* stream)
     Image r(filepath + "render.png", 4), a(filepath + "albedo.png", 4), n(filepath + "normal.png", 4);
     if (a.shape.x != r.shape.x || a.shape.y != r.shape.y || n.shape.x != r.shape.x || n.shape.y != r.shape.y)
         throw std::runtime_error("CudaGBuffer::openImages: planes in '" + filepath + "' differ in size");
+    // first: the previous asynchronous upload may still read the staging buffer and write the device planes that
+    // allocate() is about to free
+    waitUpload();
     if (shape.x != r.shape.x || shape.y != r.shape.y) allocate(int2{ r.shape.x, r.shape.y });
     const size_t bytes = (size_t)shape.x * shape.y * 4;
-    waitUpload();                                             // the staging buffer may still feed the previous upload
     if (stageBytes < 3 * bytes) {
         if (stage) rmd_host_free_pinned(stage);
         stage = nullptr; stageBytes = 0;

@@ -154,8 +154,7 @@ class ShardedDenoiser:
     (like T and V) runs underneath frame k's remaining a-trous iterations.
     """
 
-    def __init__(self, width, height, params=None, device="cuda", group=None, rank=None, world=None, pipelined=False,
-                 reserve_per_xcd=0):
+    def __init__(self, width, height, params=None, device="cuda", group=None, rank=None, world=None, pipelined=False):
         from . import svgf  # needs librmd.so; the plan/exchange helpers above do not
         self.svgf = svgf
         self.group = group
@@ -165,7 +164,7 @@ class ShardedDenoiser:
         self.plan = make_plan(height, self.world, self.rank, svgf.frame_reach(self.params))
         self.width, self.height = width, height
         self.den = svgf.SvgfDenoiser(width, height, self.plan.buf_row0, self.plan.buf_rows, self.params, device,
-                                     pipelined=pipelined, reserve_per_xcd=reserve_per_xcd if pipelined else 0)
+                                     pipelined=pipelined)
         self.exchange = self.world > 1 and dist.is_initialized()
         self._halo_pending = False
 

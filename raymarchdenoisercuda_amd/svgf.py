@@ -5,7 +5,6 @@ torch supplies device memory (float32 CUDA tensors) and nothing else; every pass
 HIP kernels of librmd.so.
 """
 import ctypes as C
-import os
 import sys
 
 import torch
@@ -129,25 +128,6 @@ def demodulate(radiance, albedo, eps=1e-3, out=None, stream=None):
     return out
 
 
-_partition_streams = {}
-
-
-def partition_streams(device, reserve_per_xcd):
-    """(a-trous stream, T+V stream, CUs of the first, CUs of the second) of rmd_stream_create_partition, created
-    once per device and split and kept for the life of the process: torch's caching allocator records events on
-    every stream a tensor was used on (record_stream) and may do so after a denoiser is gone."""
-    index = torch.device(device).index
-    index = torch.cuda.current_device() if index is None else index
-    key = (index, reserve_per_xcd)
-    if key not in _partition_streams:
-        with torch.cuda.device(index):
-            sa, sb, na, nb = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
-            check(lib.rmd_stream_create_partition(C.byref(sa), reserve_per_xcd, 0, C.byref(na)))
-            check(lib.rmd_stream_create_partition(C.byref(sb), reserve_per_xcd, 1, C.byref(nb)))
-        _partition_streams[key] = (sa.value, sb.value, na.value, nb.value)
-    return _partition_streams[key]
-
-
 class SvgfDenoiser:
     """Cross-frame SVGF state for one device / one row strip.
 
@@ -159,14 +139,10 @@ class SvgfDenoiser:
     (HBM-bound) is issued on a second stream as soon as frame k's history is complete (after its
     a-trous iteration `hist_iteration`) and runs underneath frame k's remaining a-trous iterations
     (ALU-bound).  Same kernels, same bits; results are valid after `synchronize()`.
-    reserve_per_xcd=N (4, 8 ...) additionally splits the CUs between the two streams
-    (rmd_stream_create_partition): T+V get N CUs of every XCD, the a-trous launches the rest and size
-    their bands for that many CUs -- the two kinds of launch then really run side by side instead of
-    competing for the same wave slots (a-trous workgroups fill the register files of the CUs they are on).
     """
 
     def __init__(self, width, height, buf_row0=0, buf_rows=None, params=None, device="cuda", debug=False,
-                 collect_stats=False, pipelined=False, reserve_per_xcd=0):
+                 collect_stats=False, pipelined=False):
         self.width, self.height = width, height
         self.buf_row0 = buf_row0
         self.buf_rows = height if buf_rows is None else buf_rows
@@ -191,24 +167,12 @@ class SvgfDenoiser:
         if pipelined:
             # The a-trous stream is the high-priority queue (measured: no effect on how the dispatcher
             # arbitrates between T's pending workgroups and a new a-trous launch; kept as the intent).
-            self._params_a = self.params
-            if reserve_per_xcd:
-                sa, sb, na, nb = partition_streams(device, reserve_per_xcd)
-                self.stream_a = torch.cuda.ExternalStream(sa, device=device)   # a-trous iterations: na CUs
-                self.stream_b = torch.cuda.ExternalStream(sb, device=device)   # T + V (+ the halo exchange): nb CUs
-                self.cu_split = (na, nb)
-                self._params_a = SvgfParams.from_buffer_copy(self.params)
-                self._params_a.atrous_cus = na
-            else:
-                self.stream_a = torch.cuda.Stream(device=device, priority=-1)       # a-trous iterations
-                self.stream_b = torch.cuda.Stream(device=device, priority=0)        # T + V (+ the history halo exchange)
+            self.stream_a = torch.cuda.Stream(device=device, priority=-1)       # a-trous iterations
+            self.stream_b = torch.cuda.Stream(device=device, priority=0)        # T + V (+ the history halo exchange)
             self._ev_hist, self._ev_tv = C.c_void_p(), C.c_void_p()
             check(lib.rmd_event_create(C.byref(self._ev_hist)))
             check(lib.rmd_event_create(C.byref(self._ev_tv)))
             self._hist_recorded = False
-            # Experiment knob: T and V as N persistent workgroups (rmd_svgf_params.tv_workgroups) while
-            # they run underneath a-trous launches.  Off by default: measured slower.
-            self._tv_workgroups = int(os.environ.get("RMD_TV_WORKGROUPS", "0"))
 
     def __del__(self):
         if sys.is_finalizing():            # the HIP runtime may already be gone: leave streams and events to the process exit
@@ -270,23 +234,16 @@ class SvgfDenoiser:
             for t in (color, nd, motion, out):
                 t.record_stream(sa)
                 t.record_stream(sb)
-            self._params_tv = SvgfParams.from_buffer_copy(self.params)
-            if self._params_tv.tv_workgroups == 0:
-                self._params_tv.tv_workgroups = self._tv_workgroups
             sb.wait_stream(torch.cuda.current_stream())            # the caller's inputs
             if self._hist_recorded:                                # frame k's history complete (after its A_hist)
                 check(lib.rmd_stream_wait_event(sb.cuda_stream, self._ev_hist))
             with torch.cuda.stream(sb):
                 if before_tv is not None:
                     before_tv()
-                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(self._params_tv), row0, row1, sb.cuda_stream))
+                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(self.params), row0, row1, sb.cuda_stream))
             check(lib.rmd_event_record(self._ev_tv, sb.cuda_stream))
             check(lib.rmd_stream_wait_event(sa.cuda_stream, self._ev_tv))
-            if self._params_a is not self.params:                  # follow changes the caller made to .params
-                cus = self._params_a.atrous_cus
-                self._params_a = SvgfParams.from_buffer_copy(self.params)
-                self._params_a.atrous_cus = cus
-            check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(self._params_a), row0, row1, sa.cuda_stream, self._ev_hist))
+            check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(self.params), row0, row1, sa.cuda_stream, self._ev_hist))
             self._hist_recorded = True
         self.cur ^= 1
         self.has_history = True

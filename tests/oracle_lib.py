@@ -14,8 +14,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 
-sys.path.insert(0, ROOT)
-from raymarchdenoisercuda_amd._lib import SvgfFrameDesc, SvgfParams, SynthDesc  # noqa: E402  (struct layouts only)
 
 
 def build_oracle():
@@ -29,9 +27,54 @@ def build_oracle():
     return ORACLE_SO
 
 
+def structs_from_layout(text):
+    """ctypes structures built from oracle/abi_probe.c's report of include/rmd_api.h as the C compiler lays it out
+    (offsetof / sizeof per field) -- independently of the product's Python binding, so that a wrong field order in
+    raymarchdenoisercuda_amd/_lib.py cannot be wrong identically on the oracle's side (tests/test_abi.py compares the two)."""
+    scalar = {"i": C.c_int, "u": C.c_uint32, "f": C.c_float, "b": C.c_ubyte, "p": C.c_void_p}
+    out, name, size, fields = {}, None, 0, []
+
+    def close():
+        if name is None:
+            return
+        ct, pos, pad = [], 0, 0
+        for fname, off, fsize, kind in fields:
+            if off > pos:
+                ct.append((f"_pad{pad}", C.c_ubyte * (off - pos)))
+                pad += 1
+            base = out[kind[2:]] if kind.startswith("s:") else scalar[kind]
+            n = fsize // C.sizeof(base)
+            assert n * C.sizeof(base) == fsize, (name, fname)
+            ct.append((fname, base if n == 1 else base * n))
+            pos = off + fsize
+        cls = type(name, (C.Structure,), {"_fields_": ct})
+        assert C.sizeof(cls) == size, (name, C.sizeof(cls), size)
+        for fname, off, fsize, _ in fields:
+            assert getattr(cls, fname).offset == off and getattr(cls, fname).size == fsize, (name, fname)
+        out[name] = cls
+
+    for line in text.splitlines():
+        if not line.strip():
+            continue
+        parts = line.split()
+        if line[0] != " ":
+            close()
+            name, size, fields = parts[0], int(parts[1]), []
+        else:
+            fields.append((parts[0], int(parts[1]), int(parts[2]), parts[3]))
+    close()
+    return out
+
+
 def _load():
     build_oracle()
     lib = C.CDLL(ORACLE_SO)
+    lib.orc_abi_layout.restype = C.c_char_p
+    global ABI_LAYOUT, STRUCTS, SvgfFrameDesc, SvgfParams, SynthDesc, FilterParamsC
+    ABI_LAYOUT = lib.orc_abi_layout().decode()
+    STRUCTS = structs_from_layout(ABI_LAYOUT)
+    SvgfFrameDesc, SvgfParams, SynthDesc = STRUCTS["rmd_svgf_frame_desc"], STRUCTS["rmd_svgf_params"], STRUCTS["rmd_synth_desc"]
+    FilterParamsC = STRUCTS["rmd_filter_params"]
     P = C.c_void_p
     lib.orc_box_level.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.orc_box_filter.argtypes = [P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -63,7 +106,26 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def default_params() -> SvgfParams:
+def _by_name(cls, obj):
+    """`obj` as the oracle's own structure `cls`.  A structure of the product binding (raymarchdenoisercuda_amd._lib)
+    is copied FIELD BY FIELD BY NAME, never as bytes: if the binding's layout were wrong, the oracle would still get
+    the values the test set by name and the parity test would fail instead of agreeing on the wrong meaning."""
+    if obj is None or isinstance(obj, cls):
+        return obj
+    out = cls()
+    names = [n for n, _ in cls._fields_ if not n.startswith("_pad")]
+    assert names == [n for n, _ in obj._fields_], (cls.__name__, "field names differ from the binding's")
+    for n in names:
+        v = getattr(obj, n)
+        if hasattr(v, "__len__"):
+            for k in range(len(v)):
+                getattr(out, n)[k] = v[k]
+        else:
+            setattr(out, n, v)
+    return out
+
+
+def default_params():
     """SURVEY Appendix A defaults (kept independent of librmd's rmd_svgf_default_params; a test compares them)."""
     return SvgfParams(alpha_color=0.05, alpha_moments=0.2, h_max=32, k_z=10.0, k_n=0.9, max_motion_rows=64,
                       var_h_threshold=4, var_radius=3, sigma_n=128.0, sigma_z=1.0, sigma_l=4.0,
@@ -95,7 +157,7 @@ def weighted_filter(render_rgba: np.ndarray, params, normal=None, albedo=None) -
     alb = None if albedo is None else np.ascontiguousarray(albedo)
     lib.orc_weighted_filter.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_void_p]
     lib.orc_weighted_filter.restype = None
-    lib.orc_weighted_filter(_p(src), _p(out), _p(b0), _p(b1), _p(nrm), _p(alb), w, h, C.byref(params))
+    lib.orc_weighted_filter(_p(src), _p(out), _p(b0), _p(b1), _p(nrm), _p(alb), w, h, C.byref(_by_name(FilterParamsC, params)))
     return out
 
 
@@ -126,25 +188,25 @@ class Frame:
         d.ping[0], d.ping[1] = self.ping[0].ctypes.data, self.ping[1].ctypes.data
 
 
-def temporal(fr: Frame, p: SvgfParams, row0=0, row1=None):
-    lib.orc_svgf_temporal(C.byref(fr.desc), C.byref(p), row0, fr.height if row1 is None else row1)
+def temporal(fr: Frame, p, row0=0, row1=None):
+    lib.orc_svgf_temporal(C.byref(fr.desc), C.byref(_by_name(SvgfParams, p)), row0, fr.height if row1 is None else row1)
 
 
-def variance(fr: Frame, p: SvgfParams, row0=0, row1=None):
-    lib.orc_svgf_variance(C.byref(fr.desc), C.byref(p), row0, fr.height if row1 is None else row1)
+def variance(fr: Frame, p, row0=0, row1=None):
+    lib.orc_svgf_variance(C.byref(fr.desc), C.byref(_by_name(SvgfParams, p)), row0, fr.height if row1 is None else row1)
 
 
-def atrous(fr: Frame, p: SvgfParams, iteration, src: np.ndarray, dst: np.ndarray, row0=0, row1=None):
+def atrous(fr: Frame, p, iteration, src: np.ndarray, dst: np.ndarray, row0=0, row1=None):
     assert src.dtype == np.float32 and dst.dtype == np.float32 and src.flags.c_contiguous and dst.flags.c_contiguous
-    lib.orc_svgf_atrous(C.byref(fr.desc), C.byref(p), iteration, _p(src), _p(dst), row0, fr.height if row1 is None else row1)
+    lib.orc_svgf_atrous(C.byref(fr.desc), C.byref(_by_name(SvgfParams, p)), iteration, _p(src), _p(dst), row0, fr.height if row1 is None else row1)
 
 
-def frame(fr: Frame, p: SvgfParams, threads=1):
-    lib.orc_svgf_frame(C.byref(fr.desc), C.byref(p), threads)
+def frame(fr: Frame, p, threads=1):
+    lib.orc_svgf_frame(C.byref(fr.desc), C.byref(_by_name(SvgfParams, p)), threads)
 
 
-def pass_mt(fr: Frame, p: SvgfParams, which, iteration=0, src=None, dst=None, threads=1):
-    lib.orc_svgf_pass_mt(C.byref(fr.desc), C.byref(p), which, iteration, _p(src), _p(dst), threads)
+def pass_mt(fr: Frame, p, which, iteration=0, src=None, dst=None, threads=1):
+    lib.orc_svgf_pass_mt(C.byref(fr.desc), C.byref(_by_name(SvgfParams, p)), which, iteration, _p(src), _p(dst), threads)
 
 
 def synth_gbuffer(width, height, frame_index, buf_row0=0, buf_rows=None, seed=1234, pan=(1.25, -0.5), want_albedo=False):

@@ -36,6 +36,38 @@ def test_struct_layouts_match_the_reference(rmd):
     assert p.cacheInput == 1 and p.cacheBuffer == 1 and p.type == rmd.FilterParams.AVERAGE
 
 
+def test_python_binding_matches_the_c_layout_of_the_header(rmd, orc):
+    """raymarchdenoisercuda_amd/_lib.py against include/rmd_api.h as a C compiler lays it out (oracle/abi_probe.c:
+    offsetof / sizeof of every field): same field names in the same order at the same offsets with the same sizes.
+    The oracle's front end builds its structures from that report, not from the binding (tests/oracle_lib.py)."""
+    from raymarchdenoisercuda_amd import _lib
+    pairs = {"rmd_int2": _lib.Int2, "rmd_gbuffer": _lib.GBuffer, "rmd_filter_params": _lib.FilterParams,
+             "rmd_svgf_params": _lib.SvgfParams, "rmd_svgf_frame_desc": _lib.SvgfFrameDesc, "rmd_strip_plan": _lib.StripPlan,
+             "rmd_halo_step": _lib.HaloStep, "rmd_synth_desc": _lib.SynthDesc}
+    assert sorted(pairs) == sorted(orc.STRUCTS)
+    kinds = {C.c_int: "i", C.c_uint32: "u", C.c_float: "f", C.c_ubyte: "b", C.c_void_p: "p"}
+    struct, seen = None, {}
+    for line in orc.ABI_LAYOUT.splitlines():
+        parts = line.split()
+        if line[0] != " ":
+            struct = parts[0]
+            assert C.sizeof(pairs[struct]) == int(parts[1]) and C.alignment(pairs[struct]) == int(parts[2]), struct
+            seen[struct] = []
+            continue
+        name, off, size, kind = parts[0], int(parts[1]), int(parts[2]), parts[3]
+        seen[struct].append(name)
+        field = getattr(pairs[struct], name)
+        assert (field.offset, field.size) == (off, size), f"{struct}.{name}: binding {(field.offset, field.size)} vs C {(off, size)}"
+        ctype = dict(pairs[struct]._fields_)[name]
+        ctype = getattr(ctype, "_type_", ctype) if hasattr(ctype, "_length_") else ctype
+        if kind.startswith("s:"):
+            assert ctype is pairs[kind[2:]], f"{struct}.{name}"
+        else:
+            assert kinds[ctype] == kind, f"{struct}.{name}: binding {ctype} vs C kind {kind}"
+    for struct, names in seen.items():
+        assert names == [n for n, _ in pairs[struct]._fields_], struct
+
+
 def test_default_params_match_appendix_a(rmd, orc):
     a, b = rmd.default_params(), orc.default_params()
     for name, _ in a._fields_:

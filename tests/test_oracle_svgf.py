@@ -239,3 +239,48 @@ def test_demodulation_by_hand(orc):
     got = orc.demodulate(rad, alb, eps=1e-3)
     want = np.array([[[2.0, 0.25, 0.0, 0.7], [2.0, 1000.0, 0.5, 0.1]]], np.float32)
     assert np.allclose(got, want, rtol=1e-6)
+
+
+def test_variance_spatial_estimate_by_hand(orc):
+    """V on a 3x3 frame (Appendix A.V): the centre pixel has h = 2 < 4, so it takes the 7x7 spatial estimate -- of which
+    only the 3x3 frame exists (out-of-frame taps skipped and renormalised).  Flat plane (same normal, w_n = 1), depth
+    varies along x only: g_z(centre) = |z(2,1) - z(1,1)| + |z(1,2) - z(1,1)| = 0.25; weights w = exp(-|dz| / (sigma_z
+    g_z len + 1e-8)), no luminance term.  variance = max(0, E[l^2] - E[l]^2) * 4 / h; colour = weighted mean.
+    A pixel with h = 4 passes through untouched."""
+    p = orc.default_params()
+    nd = np.zeros((3, 3, 4), np.float32)
+    nd[..., 2] = 1.0
+    nd[..., 3] = np.array([4.0, 4.25, 4.5], np.float32)[None, :]          # z depends on x only
+    t_color = np.zeros((3, 3, 4), np.float32)
+    grey = np.array([[1.0, 2.0, 4.0], [0.5, 1.0, 3.0], [2.0, 2.0, 0.25]], np.float64)
+    t_color[..., :3] = grey[..., None].astype(np.float32) * np.array([1.0, 0.5, 2.0], np.float32)   # r, g, b = l', l'/2, 2 l'
+    t_color[..., 3] = 0.125
+    t_mom = np.zeros((3, 3, 4), np.float32)
+    t_mom[..., 2] = 4.0                                                    # everybody has a long history ...
+    t_mom[1, 1, 2] = 2.0                                                   # ... except the centre
+    f = orc.Frame(3, 3, t_color, nd, np.zeros((3, 3, 2), np.float32))
+    f.t_color[...] = t_color
+    f.t_moments[...] = t_mom
+    orc.variance(f, p)
+    # by hand, in float64
+    gz, zc = 0.25, 4.25
+    sw = sl = sl2 = 0.0
+    sc = np.zeros(3)
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            x, y = 1 + dx, 1 + dy
+            length = np.sqrt(dx * dx + dy * dy)
+            wz = abs(zc - float(nd[y, x, 3])) / (1.0 * gz * length + 1e-8) if (dx or dy) else 0.0
+            w = np.exp(-wz)
+            rgb = t_color[y, x, :3].astype(np.float64)
+            lum = float(LUM @ rgb)
+            sw += w; sc += w * rgb; sl += w * lum; sl2 += w * lum * lum
+    want_var = max(0.0, sl2 / sw - (sl / sw) ** 2) * 4.0 / 2.0
+    assert np.allclose(f.v_color[1, 1, :3], sc / sw, rtol=1e-5)
+    assert np.isclose(f.v_color[1, 1, 3], want_var, rtol=1e-4)
+    # the two taps on the centre column (dx = 0) have dz = 0 and weight exactly 1; the others exp(-0.25 / (0.25 len)):
+    # exp(-1) beside the centre, exp(-1/sqrt 2) on the diagonals
+    assert np.isclose(sw, 3.0 + 2.0 * np.exp(-1.0) + 4.0 * np.exp(-1.0 / np.sqrt(2.0)), rtol=1e-6)
+    others = np.ones((3, 3), bool)
+    others[1, 1] = False
+    assert (f.v_color[others] == t_color[others]).all()                   # h >= var_h_threshold: pass-through, bit for bit

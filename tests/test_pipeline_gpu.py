@@ -11,8 +11,8 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def run_sequence(rmd, width, height, frames, pipelined, p, reserve_per_xcd=0):
-    den = rmd.SvgfDenoiser(width, height, params=p, pipelined=pipelined, reserve_per_xcd=reserve_per_xcd)
+def run_sequence(rmd, width, height, frames, pipelined, p):
+    den = rmd.SvgfDenoiser(width, height, params=p, pipelined=pipelined)
     inputs = [rmd.svgf.synth_gbuffer(width, height, f) for f in range(frames)]
     torch.cuda.synchronize()
     outs = [torch.empty_like(inputs[0][0]) for _ in range(frames)]
@@ -36,29 +36,7 @@ def test_pipelined_frames_equal_serial_frames(rmd, cuda, width, height):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("reserve", [4, 16])
-def test_cu_partition_streams_change_no_bit(rmd, cuda, reserve):
-    """rmd_stream_create_partition: T+V on `reserve` CUs of every XCD, the a-trous launches (sized through
-    rmd_svgf_params.atrous_cus) on the others.  Same kernels, fewer CUs each: identical frames."""
-    p = rmd.default_params()
-    p.max_motion_rows = 8
-    serial, den_s = run_sequence(rmd, 1920, 1080, 6, False, p)
-    split, den_p = run_sequence(rmd, 1920, 1080, 6, True, p, reserve_per_xcd=reserve)
-    assert den_p.cu_split == (256 - 8 * reserve, 8 * reserve)
-    for f, (a, b) in enumerate(zip(serial, split)):
-        assert torch.equal(a, b), f"frame {f}: {(a != b).sum().item()} values differ"
-    for a, b in zip(den_s.history(), den_p.history()):
-        assert torch.equal(a, b)
-
-
-def test_cu_partition_arguments(rmd, cuda):
-    import ctypes
-    s = ctypes.c_void_p()
-    for bad in ((0, 0), (3, 0), (32, 0), (8, 2)):
-        assert rmd.lib.rmd_stream_create_partition(ctypes.byref(s), bad[0], bad[1], None) != 0
-    assert rmd.lib.rmd_stream_create_partition(None, 8, 0, None) != 0
-
-
+@pytest.mark.experiments
 @pytest.mark.parametrize("workgroups", [1, 7, 256, 5000])
 def test_persistent_tv_grids_equal_one_workgroup_per_tile(rmd, cuda, workgroups):
     """rmd_svgf_params.tv_workgroups: T and V as N persistent workgroups walking the tiles give the
