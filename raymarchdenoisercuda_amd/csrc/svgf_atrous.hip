@@ -569,23 +569,27 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     // ---- one step: this thread's outputs are lattice rows jw (A) and jw+1 (B), jw = j + 2*pr
     auto compute = [&](const int j) {
         const int jw = j + 2 * pr;
-        int rb[6];
+        // Window rows jw-2 .. jw+3 sit in ring slots slot_of(jw-2) + tr (mod NR).  jw is even and NR is even, so the rows
+        // come in three pairs that never straddle the wrap: one address register per PAIR, the odd row of a pair is an
+        // immediate offset (3 VGPRs instead of 6 across the tap loop).
+        int rbp[3];
         {
             int slot = slot_of(jw - 2);
 #pragma unroll
-            for (int tr = 0; tr < 6; ++tr) {
-                rb[tr] = slot * C::ROW_BYTES + col * 16;
-                slot = slot == C::NR - 1 ? 0 : slot + 1;
+            for (int q = 0; q < 3; ++q) {
+                rbp[q] = slot * C::ROW_BYTES + col * 16;
+                slot = slot >= C::NR - 2 ? slot + 2 - C::NR : slot + 2;
             }
         }
+        auto rb = [&](const int tr) { return rbp[tr >> 1] + (tr & 1) * C::ROW_BYTES; };
         const int yA = ybase + jw * S, yB = yA + S;
         Tap cA, cB;
-        cA.c = lds_f4(lds, rb[2] + 2 * S * 16); cA.n = lds_f4(lds, C::PLANE_BYTES + rb[2] + 2 * S * 16);
-        cB.c = lds_f4(lds, rb[3] + 2 * S * 16); cB.n = lds_f4(lds, C::PLANE_BYTES + rb[3] + 2 * S * 16);
+        cA.c = lds_f4(lds, rb(2) + 2 * S * 16); cA.n = lds_f4(lds, C::PLANE_BYTES + rb(2) + 2 * S * 16);
+        cB.c = lds_f4(lds, rb(3) + 2 * S * 16); cB.n = lds_f4(lds, C::PLANE_BYTES + rb(3) + 2 * S * 16);
         Center<float> kA, kB;
         CenterAux xA, xB;
-        setup(0, yA, rb[2], cA, kA, xA);
-        setup(1, yB, rb[3], cB, kB, xB);
+        setup(0, yA, rb(2), cA, kA, xA);
+        setup(1, yB, rb(3), cB, kB, xB);
         const Center<f2> kAB = pack(kA, kB);
         kA = Center<float>{ kAB.nx.x, kAB.ny.x, kAB.nz.x, kAB.z.x, kAB.lum.x, kAB.il.x };   // lanes, not copies
         kB = Center<float>{ kAB.nx.y, kAB.ny.y, kAB.nz.y, kAB.z.y, kAB.lum.y, kAB.il.y };
@@ -612,7 +616,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             const int dxi = grp / (6 / GR), tr0 = (grp % (6 / GR)) * GR;
 #pragma unroll
             for (int q = 0; q < GR; ++q) {
-                const int off = rb[tr0 + q] + (2 * S + (dxi - 2) * S) * 16;
+                const int off = rb(tr0 + q) + (2 * S + (dxi - 2) * S) * 16;
                 t[q].c = lds_f4(lds, off);
                 t[q].n = lds_f4(lds, C::PLANE_BYTES + off);
             }
@@ -658,8 +662,13 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         // Per-pixel sums = (row only this pixel taps: dy=-2 for role A, dy=+2 for role B) + (the four
         // rows shared with its partner), each summed dx outer / dy inner.  The direct kernel groups
         // its 25 taps the same way, so the two variants stay bit-identical.
-        outA = finish(sA.sw + sAB.sw.x, sA.sl + sAB.sl.x, sA.sr + sAB.sr.x, sA.sg + sAB.sg.x, sA.sv + sAB.sv.x, cA.c);
-        outB = finish(sB.sw + sAB.sw.y, sB.sl + sAB.sl.y, sB.sr + sAB.sr.y, sB.sg + sAB.sg.y, sB.sv + sAB.sv.y, cB.c);
+        // The centre colours are only needed again for the pass-through case of finish(): re-read from the ring (through an
+        // address the optimizer cannot prove equal, or it keeps the first copy) instead of held in 8 VGPRs across the tap loop.
+        int ra = rb(2), rbb = rb(3);
+        asm volatile("" : "+v"(ra), "+v"(rbb));
+        const float4 ccA = lds_f4(lds, ra + 2 * S * 16), ccB = lds_f4(lds, rbb + 2 * S * 16);
+        outA = finish(sA.sw + sAB.sw.x, sA.sl + sAB.sl.x, sA.sr + sAB.sr.x, sA.sg + sAB.sg.x, sA.sv + sAB.sv.x, ccA);
+        outB = finish(sB.sw + sAB.sw.y, sB.sl + sAB.sl.y, sB.sr + sAB.sr.y, sB.sg + sAB.sg.y, sB.sv + sAB.sv.y, ccB);
     };
     // The two output pixels of step j are written AFTER the ring refill of the step: the refill has to
     // wait for the prefetch loads (vmcnt), and stores issued before it would be waited for as well.
