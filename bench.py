@@ -9,7 +9,7 @@ HBM before the timed region (all W+K frames of G-buffer are pre-generated on the
   N = 1 : BASELINE.json configs[2], 3840x2160 synthetic G-buffer + radiance, fp32.
   N > 1 : BASELINE.json configs[3], the fixed 7680x4320 (8K) frame cut into N row strips of 4320/N
           rows, one per GPU (STRONG scaling); ranks exchange the history halo rows with rank+-1
-          over RCCL every frame (sharding.py).  Rank 0 also times the unsharded 8K frame on its
+          over RCCL every frame, plus ONE exchange inside the frame (a-trous iteration 3's halo rows), sharding.py.  Rank 0 also times the unsharded 8K frame on its
           own GPU after the timed region (`one_gpu_same_frame`), so the speed-up is on one workload.
 Without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) the parent starts
 the N ranks itself as child processes BEFORE anything touches the GPU, relays rank 0's JSON line
@@ -141,7 +141,7 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps):
     rmd.check(rmd.lib.rmd_timer_create(C.byref(timer)))
     ms = C.c_float()
     out = torch.empty_like(frames[0][0])
-    reach = rmd.svgf.frame_reach(p)
+    it_reach = rmd.svgf.frame_iteration_reach(p)     # rows beyond the strip each iteration is computed on (rmd_svgf_frame)
     H = den.height
     sums, launch_px = [0.0] * n, [0] * n
     for rep in range(reps + 2):
@@ -156,8 +156,7 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps):
                 dst = den.hist_color[den.cur ^ 1]
             else:
                 dst, pp = den.ping[pp], pp ^ 1
-            ra = sum(2 * (1 << k) for k in range(it + 1, n))          # rows later iterations tap (rmd_svgf_frame)
-            a0, a1 = max(0, row0 - ra), min(H, row1 + ra)
+            a0, a1 = max(0, row0 - it_reach[it]), min(H, row1 + it_reach[it])
             rmd.check(rmd.lib.rmd_timer_start(timer, None))
             rmd.svgf.atrous(desc, p, it, src, dst, a0, a1)
             rmd.check(rmd.lib.rmd_timer_stop(timer, None))
@@ -385,13 +384,17 @@ def main():
     p = rmd.default_params()
     p.max_motion_rows = 8            # the synthetic pan moves <= 1.5 rows per frame
     p.atrous_variant = int(os.environ.get("RMD_ATROUS_VARIANT", "0"))   # 0 = library default (experiments only)
-    # Default: the 7 launches of a frame back to back on one stream, so the per-kernel durations of a
+    # Default (every N): the 7 launches of a frame back to back on one stream, so the per-kernel durations of a
     # rocprofv3 run of this command are those of isolated launches (what `roofline` prices).
     # RMD_PIPELINE=1 software-pipelines consecutive frames over two HIP streams (T+V of frame k+1
-    # under the a-trous iterations of frame k): +4 % frames/s, but the overlapped launches share CUs.
-    # With N > 1 the second stream is on by default: it carries the RCCL history halo exchange, which
-    # then runs underneath the a-trous iterations instead of in front of the next frame.
-    pipelined = os.environ.get("RMD_PIPELINE", "1" if world > 1 else "0") == "1"
+    # under the a-trous iterations of frame k): measured SLOWER on one GPU (round 3: 9260 against 9620 Mpix/s), so it is
+    # not the default for any N; with N > 1 the exchanges have a stream of their own either way.
+    pipelined = os.environ.get("RMD_PIPELINE", "0") == "1"
+    # N > 1: ONE neighbour exchange inside the frame (a-trous iteration 3's 32 halo rows per side, 3.9 MB at 8K, beside the
+    # interior rows of iteration 4) instead of redundant rows only: T, V, A0..A2 run on 32 fewer rows per side
+    # (sharding.ShardedDenoiser; RMD_EXCHANGE_ITERATION=-1 switches it off).  The exchanges run on a second stream.
+    if world > 1 and not pipelined:
+        p.exchange_iteration = int(os.environ.get("RMD_EXCHANGE_ITERATION", "3"))
     sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world, pipelined=pipelined)
     plan = sd.plan
     rows_out = plan.row1 - plan.row0
@@ -460,8 +463,12 @@ def main():
         "bytes_per_px": {"algorithmic_per_pass_sum": FULL_BYTES_PER_PX, "moved_with_V_fused_into_T": MOVED_BYTES_PER_PX},
     }
     if world > 1:
-        result["halo_bytes_per_frame_rank0"] = sharding.halo_bytes(plan, width)
+        result["halo_bytes_per_frame_rank0"] = {"history": sharding.halo_bytes(plan, width), "mid_frame": sharding.mid_halo_bytes(plan, width)}
         result["config"]["redundant_rows_per_side"] = {"inputs": plan.reach_in, "history": plan.reach_hist}
+        result["config"]["exchange_iteration"] = plan.mid_iteration
+        result["config"]["exchanges"] = ("history halo after A0 + a-trous iteration %d's %d halo rows per side, both on a second stream "
+                                         "beside the a-trous launches" % (plan.mid_iteration, plan.mid_rows)) if plan.mid_iteration >= 0 \
+            else "history halo after A0 on a second stream; redundant rows instead of any exchange inside the frame"
 
     if rank == 0:
         result["roofline"] = measure_roofline(rmd, torch, sd.den, frames, width, rows_out, plan, args.roofline_reps)

@@ -148,6 +148,14 @@ typedef struct rmd_svgf_params {
                                    persistent workgroups that walk the tiles; same results, measured slower     */
     int   atrous_cus;       /* 0   CUs the a-trous launches may count on when they size their bands (0 = all CUs of
                                    the device; fewer when the caller knows other work holds part of the device)  */
+    /* row strips across GPUs (SURVEY §8e "Halo sizes") */
+    int   exchange_iteration; /* -1  every pass runs on the redundant rows the later passes tap, no exchange inside a frame |
+                                   X in [0, iterations-2]: a strip computes iteration X on its OWN rows only and receives the
+                                   2*(2^(X+1) + ... + 2^(iterations-1)) rows beyond them from rank +-1 (ONE neighbour exchange
+                                   per frame); T, V and the iterations in front of X then run on that many fewer rows.
+                                   Whole-frame calls are unaffected.  Strips drive the frame in parts
+                                   (rmd_svgf_frame_atrous_part) so that iteration X+1 starts on its interior rows while the
+                                   halo travels                                                                 */
 } rmd_svgf_params;
 
 void rmd_svgf_default_params(rmd_svgf_params* p);
@@ -216,6 +224,25 @@ int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int r
 int rmd_svgf_frame_tv(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);
 int rmd_svgf_frame_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
                           void* history_ready_event);
+/* The a-trous iterations of a strip whose params name an exchange_iteration X, in the three parts the exchange cuts them into:
+ *   RMD_ATROUS_HEAD      iterations 0..X (X on rows [row0,row1) only).  Then the caller starts the neighbour exchange of
+ *                        the plane rmd_svgf_frame_iteration_plane(f, p, X) -- rows per side: rmd_svgf_frame_mid_exchange --
+ *                        on another stream, ordered behind an event recorded here;
+ *   RMD_ATROUS_INTERIOR  iteration X+1 on the rows that tap none of the halo (at least 2*2^(X+1) rows inside every strip
+ *                        edge that is not a frame edge): runs while the halo travels;
+ *   RMD_ATROUS_TAIL      after the exchange has completed: iteration X+1 on the remaining (boundary) rows, then X+2 ...
+ *   RMD_ATROUS_ALL       everything in order (= rmd_svgf_frame_atrous; complete only where no halo is needed: whole frames,
+ *                        or exchange_iteration = -1).
+ * Same kernels on other row ranges: bit-identical to the unsharded frame (tests/test_svgf_gpu.py, test_sharding_*). */
+enum { RMD_ATROUS_ALL = 0, RMD_ATROUS_HEAD = 1, RMD_ATROUS_INTERIOR = 2, RMD_ATROUS_TAIL = 3 };
+int rmd_svgf_frame_atrous_part(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
+                               void* history_ready_event, int part);
+/* reach[i] = rows above/below [row0,row1) on which a strip computes a-trous iteration i (0 beyond `iterations`). */
+int rmd_svgf_frame_iteration_reach(const rmd_svgf_params* p, int reach[8]);
+/* mid[0] = exchange_iteration (or -1), mid[1] = rows per side that travel in the mid-frame exchange. */
+int rmd_svgf_frame_mid_exchange(const rmd_svgf_params* p, int mid[2]);
+/* The plane iteration `iteration` writes under rmd_svgf_frame's routing (ping[] / hist_color_out / out_color). */
+int rmd_svgf_frame_iteration_plane(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration, float** plane);
 /* Rows needed / produced above and below [row0,row1) by rmd_svgf_frame (for sizing buffers and
  * halo exchanges): reach[0] = current-frame input planes read, reach[1] = history planes read,
  * reach[2] = rows on which hist_color_out is (redundantly) produced, reach[3] = same for
@@ -236,6 +263,13 @@ int  rmd_svgf_context_reset_history(rmd_svgf_context* ctx, void* stream);
 int  rmd_svgf_context_denoise(rmd_svgf_context* ctx, const rmd_svgf_params* p,
                               const float* color, const float* nd, const float* motion,
                               const float* prev_nd, float* out, int row0, int row1, void* stream);
+/* The same frame in the parts of rmd_svgf_frame_atrous_part: RMD_ATROUS_HEAD runs T + V + iterations 0..X,
+ * RMD_ATROUS_INTERIOR / RMD_ATROUS_TAIL the rest; the history planes rotate with the TAIL part.  Between HEAD and TAIL the
+ * caller exchanges the rows of rmd_svgf_context_mid_plane with rank +-1 (rmd_mid_exchange). */
+int  rmd_svgf_context_denoise_part(rmd_svgf_context* ctx, const rmd_svgf_params* p,
+                                   const float* color, const float* nd, const float* motion,
+                                   const float* prev_nd, float* out, int row0, int row1, void* stream, int part);
+int  rmd_svgf_context_mid_plane(rmd_svgf_context* ctx, const rmd_svgf_params* p, float** plane);
 /* The history planes the NEXT rmd_svgf_context_denoise call will read (for halo exchange). */
 int  rmd_svgf_context_history(rmd_svgf_context* ctx, float** hist_color, float** hist_moments);
 /* Fill a descriptor with the context's planes for the next frame (advanced use / tests). */
@@ -252,11 +286,14 @@ typedef struct rmd_strip_plan {
     int buf_row0, buf_rows;    /* rows every plane of this rank holds (strip + reach, clamped)      */
     int reach_in, reach_hist;  /* rmd_svgf_frame_reach()[0], [1]                                     */
     int have_color, have_moments; /* ...[2], [3]: history rows this rank produces beyond its strip   */
+    int mid_iteration, mid_rows;  /* rmd_svgf_frame_mid_exchange(): the a-trous iteration whose output crosses ranks inside
+                                     a frame (-1 = none) and the rows per side that travel                  */
 } rmd_strip_plan;
 enum { RMD_HALO_RECV = 0, RMD_HALO_SEND = 1, RMD_HALO_MAX_STEPS = 8 };
+enum { RMD_PLANE_HIST_COLOR = 0, RMD_PLANE_HIST_MOMENTS = 1, RMD_PLANE_MID = 2 };
 typedef struct rmd_halo_step {
     int kind;                  /* RMD_HALO_RECV | RMD_HALO_SEND                                      */
-    int plane;                 /* 0 = hist_color, 1 = hist_moments                                   */
+    int plane;                 /* RMD_PLANE_HIST_COLOR | RMD_PLANE_HIST_MOMENTS | RMD_PLANE_MID        */
     int row_lo, row_hi;        /* GLOBAL rows [row_lo,row_hi)                                        */
     int peer;                  /* rank - 1 or rank + 1                                               */
 } rmd_halo_step;
@@ -266,7 +303,10 @@ int    rmd_strip_plan_make(int height, int world, int rank, const rmd_svgf_param
 /* The exchange of one rank and frame.  Receives and the neighbour's matching sends appear in the same
  * order, so posting them as one group cannot deadlock.  steps may be NULL to count. */
 int    rmd_halo_plan(const rmd_strip_plan* plan, rmd_halo_step* steps, int max_steps, int* n_steps);
-size_t rmd_halo_bytes(const rmd_strip_plan* plan, int width);   /* bytes this rank receives per frame */
+size_t rmd_halo_bytes(const rmd_strip_plan* plan, int width);   /* history bytes this rank receives per frame */
+/* The exchange INSIDE a frame (rmd_svgf_params.exchange_iteration = X >= 0): plan->mid_rows rows of iteration X's output on
+ * either side of the strip, received from the neighbour that computed them as its own rows (plane RMD_PLANE_MID). */
+int    rmd_mid_halo_plan(const rmd_strip_plan* plan, rmd_halo_step* steps, int max_steps, int* n_steps);
 
 /* RCCL communicator (librccl.so is opened on first use; rmd_comm_available() == 0 without it).
  * Multi-process: rank 0 calls rmd_comm_unique_id and hands the 128 bytes to the other ranks (the host
@@ -286,6 +326,11 @@ int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float*
 /* Single-process form: plans[k], planes and stream of rank k for k < world, all ranks in one group. */
 int rmd_halo_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* hist_color,
                           float* const* hist_moments, void* const* streams);
+/* The mid-frame exchange (rmd_mid_halo_plan) of iteration X's output plane -- rmd_svgf_context_mid_plane /
+ * rmd_svgf_frame_iteration_plane -- between RMD_ATROUS_HEAD and RMD_ATROUS_TAIL, asynchronous on `stream` (a second
+ * stream, so that RMD_ATROUS_INTERIOR runs meanwhile). */
+int rmd_mid_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* mid_plane, void* stream);
+int rmd_mid_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* mid_planes, void* const* streams);
 /* Explicit steps on communicator comm_index of c (tests: a loop-back exchange on one GPU). */
 int rmd_halo_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
                             int width, float* hist_color, float* hist_moments, void* stream);

@@ -5,7 +5,9 @@
 //   NodeDenoiser node(width, height, params, devices);   one process driving several GPUs of a node:
 //       node.denoise(color, nd, motion, prevNd, out) runs every rank's strip on its own device and
 //       stream and then the neighbour history-halo exchange (RCCL over xGMI; ranks that share a device
-//       -- a rehearsal on one GPU -- copy the rows device-to-device by the same plan).
+//       -- a rehearsal on one GPU -- copy the rows device-to-device by the same plan).  With
+//       params.exchange_iteration = X >= 0 the frame additionally exchanges AX's halo rows in its middle
+//       (on a second stream per rank, beside the interior rows of A(X+1)) and runs T, V, A0..AX on fewer rows.
 // A multi-PROCESS host (one rank per process) uses StripPlan + SvgfContext + rmd_comm_create /
 // rmd_halo_exchange directly: INTEGRATION.md shows the loop.
 #ifndef RMD_STRIPS_H
@@ -28,6 +30,15 @@ struct StripPlan : rmd_strip_plan {
         return s;
     }
     size_t haloBytes(int width) const { return rmd_halo_bytes(this, width); }
+    // the exchange INSIDE a frame (params.exchange_iteration >= 0): mid_rows rows of iteration mid_iteration's output per side
+    std::vector<rmd_halo_step> midSteps() const
+    {
+        std::vector<rmd_halo_step> s(RMD_HALO_MAX_STEPS);
+        int n = 0;
+        rmdCheck(rmd_mid_halo_plan(this, s.data(), (int)s.size(), &n), "StripPlan::midSteps");
+        s.resize(n);
+        return s;
+    }
 };
 
 // RAII over rmd_comm (move-only)
@@ -54,6 +65,8 @@ public:
         StripPlan plan;
         std::unique_ptr<SvgfContext> ctx;
         void* stream = nullptr;
+        void* commStream = nullptr;                  // carries the mid-frame exchange beside the interior rows of the next iteration
+        void* headDone = nullptr; void* midDone = nullptr;   // events
     };
     std::vector<Rank> ranks;
 
@@ -70,6 +83,9 @@ public:
             rmdCheck(rmd_set_device(r.device), "NodeDenoiser(set device)");
             r.ctx.reset(new SvgfContext(width, height, r.plan.buf_row0, r.plan.buf_rows));
             rmdCheck(rmd_stream_create(&r.stream), "NodeDenoiser(stream)");
+            rmdCheck(rmd_stream_create(&r.commStream), "NodeDenoiser(comm stream)");
+            rmdCheck(rmd_event_create(&r.headDone), "NodeDenoiser(event)");
+            rmdCheck(rmd_event_create(&r.midDone), "NodeDenoiser(event)");
         }
         if (world > 1 && distinct) comm_ = Communicator(devices);      // RCCL: one communicator per device
     }
@@ -77,7 +93,13 @@ public:
     NodeDenoiser& operator=(const NodeDenoiser&) = delete;
     ~NodeDenoiser()
     {
-        for (Rank& r : ranks) { rmd_set_device(r.device); rmd_stream_sync(r.stream); rmd_stream_destroy(r.stream); r.ctx.reset(); }
+        for (Rank& r : ranks) {
+            rmd_set_device(r.device);
+            rmd_stream_sync(r.stream); rmd_stream_sync(r.commStream);
+            rmd_event_destroy(r.headDone); rmd_event_destroy(r.midDone);
+            rmd_stream_destroy(r.commStream); rmd_stream_destroy(r.stream);
+            r.ctx.reset();
+        }
     }
 
     // One frame: every rank's strip (asynchronous on its own stream), then the history halo for the next frame.
@@ -85,10 +107,60 @@ public:
                  const std::vector<const float*>& prevNd, const std::vector<float*>& out)
     {
         const int world = (int)ranks.size();
-        for (int k = 0; k < world; ++k) {
-            Rank& r = ranks[k];
-            rmdCheck(rmd_set_device(r.device), "NodeDenoiser::denoise(set device)");
-            r.ctx->denoise(params_, color[k], nd[k], motion[k], prevNd[k], out[k], r.plan.row0, r.plan.row1, r.stream);
+        const bool mid = world > 1 && ranks[0].plan.mid_iteration >= 0;
+        if (!mid) {
+            for (int k = 0; k < world; ++k) {
+                Rank& r = ranks[k];
+                rmdCheck(rmd_set_device(r.device), "NodeDenoiser::denoise(set device)");
+                r.ctx->denoise(params_, color[k], nd[k], motion[k], prevNd[k], out[k], r.plan.row0, r.plan.row1, r.stream);
+            }
+        } else {
+            // One neighbour exchange inside the frame: every rank's T + V + A0..AX, then AX's halo rows travel on the comm
+            // streams while A(X+1) runs on its interior rows; its boundary rows and the later iterations wait for the halo.
+            auto part = [&](int k, int which) {
+                Rank& r = ranks[k];
+                rmdCheck(rmd_set_device(r.device), "NodeDenoiser::denoise(set device)");
+                r.ctx->denoisePart(params_, color[k], nd[k], motion[k], prevNd[k], out[k], r.plan.row0, r.plan.row1, r.stream, which);
+            };
+            std::vector<float*> planes(world);
+            for (int k = 0; k < world; ++k) {
+                part(k, RMD_ATROUS_HEAD);
+                planes[k] = ranks[k].ctx->midPlane(params_);
+                rmdCheck(rmd_event_record(ranks[k].headDone, ranks[k].stream), "NodeDenoiser(head event)");
+                rmdCheck(rmd_stream_wait_event(ranks[k].commStream, ranks[k].headDone), "NodeDenoiser(comm waits for head)");
+            }
+            if (comm_.get()) {
+                std::vector<rmd_strip_plan> plans(world);
+                std::vector<void*> streams(world);
+                for (int k = 0; k < world; ++k) { plans[k] = ranks[k].plan; streams[k] = ranks[k].commStream; }
+                rmdCheck(rmd_mid_exchange_all(comm_.get(), plans.data(), width_, planes.data(), streams.data()), "NodeDenoiser(mid exchange)");
+            } else {
+                // ranks share a device (rehearsal): a receiver's comm stream also waits for the SENDER's head, then copies by plan
+                for (int k = 0; k < world; ++k)
+                    for (const rmd_halo_step& s : ranks[k].plan.midSteps()) {
+                        if (s.kind != RMD_HALO_RECV) continue;
+                        const Rank& q = ranks[s.peer];
+                        rmdCheck(rmd_stream_wait_event(ranks[k].commStream, q.headDone), "NodeDenoiser(comm waits for the sender)");
+                        float* dst = planes[k] + (size_t)(s.row_lo - ranks[k].plan.buf_row0) * width_ * 4;
+                        const float* src = planes[s.peer] + (size_t)(s.row_lo - q.plan.buf_row0) * width_ * 4;
+                        rmdCheck(rmd_memcpy_d2d(dst, src, (size_t)(s.row_hi - s.row_lo) * width_ * 16, ranks[k].commStream), "NodeDenoiser(mid copy)");
+                    }
+            }
+            for (int k = 0; k < world; ++k) {
+                rmdCheck(rmd_set_device(ranks[k].device), "NodeDenoiser::denoise(set device)");
+                rmdCheck(rmd_event_record(ranks[k].midDone, ranks[k].commStream), "NodeDenoiser(mid event)");
+            }
+            for (int k = 0; k < world; ++k) part(k, RMD_ATROUS_INTERIOR);
+            for (int k = 0; k < world; ++k) {
+                rmdCheck(rmd_set_device(ranks[k].device), "NodeDenoiser::denoise(set device)");
+                rmdCheck(rmd_stream_wait_event(ranks[k].stream, ranks[k].midDone), "NodeDenoiser(wait for the halo)");
+                // shared-device rehearsal: the neighbours' copies READ this rank's rows on THEIR comm streams; the next frame
+                // must not overwrite them earlier (with RCCL the sends are on this rank's own comm stream: midDone covers them)
+                if (!comm_.get())
+                    for (int q : { k - 1, k + 1 })
+                        if (q >= 0 && q < world) rmdCheck(rmd_stream_wait_event(ranks[k].stream, ranks[q].midDone), "NodeDenoiser(wait for the neighbour's copy)");
+                part(k, RMD_ATROUS_TAIL);
+            }
         }
         if (world == 1) return;
         std::vector<float*> hc(world), hm(world);

@@ -30,6 +30,15 @@ public:
     {
         rmdCheck(rmd_svgf_context_denoise(ctx, &p, color, nd, motion, prevNd, out, row0, row1, stream), "SvgfContext::denoise");
     }
+    // The same frame in the parts a mid-frame neighbour exchange cuts it into (rmd_svgf_params.exchange_iteration >= 0):
+    // RMD_ATROUS_HEAD = T + V + iterations 0..X, then the caller exchanges midPlane()'s halo rows, RMD_ATROUS_INTERIOR,
+    // RMD_ATROUS_TAIL (include/rmd_api.h rmd_svgf_frame_atrous_part; include/strips.h NodeDenoiser drives it).
+    void denoisePart(const SvgfParams& p, const float* color, const float* nd, const float* motion, const float* prevNd,
+                     float* out, int row0, int row1, void* stream, int part)
+    {
+        rmdCheck(rmd_svgf_context_denoise_part(ctx, &p, color, nd, motion, prevNd, out, row0, row1, stream, part), "SvgfContext::denoisePart");
+    }
+    float* midPlane(const SvgfParams& p) { float* q = nullptr; rmdCheck(rmd_svgf_context_mid_plane(ctx, &p, &q), "SvgfContext::midPlane"); return q; }
     rmd_svgf_context* get() { return ctx; }
 };
 

@@ -39,7 +39,7 @@ const char* orc_abi_layout(void)
     FIELD(rmd_svgf_params, var_h_threshold, "i"); FIELD(rmd_svgf_params, var_radius, "i");
     FIELD(rmd_svgf_params, sigma_n, "f"); FIELD(rmd_svgf_params, sigma_z, "f"); FIELD(rmd_svgf_params, sigma_l, "f");
     FIELD(rmd_svgf_params, iterations, "i"); FIELD(rmd_svgf_params, hist_iteration, "i"); FIELD(rmd_svgf_params, atrous_variant, "i");
-    FIELD(rmd_svgf_params, tv_workgroups, "i"); FIELD(rmd_svgf_params, atrous_cus, "i");
+    FIELD(rmd_svgf_params, tv_workgroups, "i"); FIELD(rmd_svgf_params, atrous_cus, "i"); FIELD(rmd_svgf_params, exchange_iteration, "i");
     BEGIN(rmd_svgf_frame_desc);
     FIELD(rmd_svgf_frame_desc, width, "i"); FIELD(rmd_svgf_frame_desc, height, "i");
     FIELD(rmd_svgf_frame_desc, buf_row0, "i"); FIELD(rmd_svgf_frame_desc, buf_rows, "i");
@@ -53,6 +53,7 @@ const char* orc_abi_layout(void)
     FIELD(rmd_strip_plan, row0, "i"); FIELD(rmd_strip_plan, row1, "i"); FIELD(rmd_strip_plan, buf_row0, "i");
     FIELD(rmd_strip_plan, buf_rows, "i"); FIELD(rmd_strip_plan, reach_in, "i"); FIELD(rmd_strip_plan, reach_hist, "i");
     FIELD(rmd_strip_plan, have_color, "i"); FIELD(rmd_strip_plan, have_moments, "i");
+    FIELD(rmd_strip_plan, mid_iteration, "i"); FIELD(rmd_strip_plan, mid_rows, "i");
     BEGIN(rmd_halo_step);
     FIELD(rmd_halo_step, kind, "i"); FIELD(rmd_halo_step, plane, "i"); FIELD(rmd_halo_step, row_lo, "i");
     FIELD(rmd_halo_step, row_hi, "i"); FIELD(rmd_halo_step, peer, "i");

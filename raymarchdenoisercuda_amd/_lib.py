@@ -55,7 +55,7 @@ class SvgfParams(C.Structure):
                 ("var_h_threshold", C.c_int), ("var_radius", C.c_int),
                 ("sigma_n", C.c_float), ("sigma_z", C.c_float), ("sigma_l", C.c_float),
                 ("iterations", C.c_int), ("hist_iteration", C.c_int), ("atrous_variant", C.c_int),
-                ("tv_workgroups", C.c_int), ("atrous_cus", C.c_int)]
+                ("tv_workgroups", C.c_int), ("atrous_cus", C.c_int), ("exchange_iteration", C.c_int)]
 
 
 class SvgfFrameDesc(C.Structure):
@@ -71,11 +71,12 @@ class StripPlan(C.Structure):
     """include/rmd_api.h rmd_strip_plan (mirrors sharding.StripPlan)."""
     _fields_ = [("height", C.c_int), ("world", C.c_int), ("rank", C.c_int), ("row0", C.c_int), ("row1", C.c_int),
                 ("buf_row0", C.c_int), ("buf_rows", C.c_int), ("reach_in", C.c_int), ("reach_hist", C.c_int),
-                ("have_color", C.c_int), ("have_moments", C.c_int)]
+                ("have_color", C.c_int), ("have_moments", C.c_int), ("mid_iteration", C.c_int), ("mid_rows", C.c_int)]
 
 
 class HaloStep(C.Structure):
     RECV, SEND = 0, 1
+    PLANE_HIST_COLOR, PLANE_HIST_MOMENTS, PLANE_MID = 0, 1, 2
     _fields_ = [("kind", C.c_int), ("plane", C.c_int), ("row_lo", C.c_int), ("row_hi", C.c_int), ("peer", C.c_int)]
 
 
@@ -99,17 +100,26 @@ SYMBOLS = {
     "rmd_svgf_frame": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
     "rmd_svgf_frame_tv": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
     "rmd_svgf_frame_atrous": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P, _P]),
+    "rmd_svgf_frame_atrous_part": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P, _P, C.c_int]),
+    "rmd_svgf_frame_mid_exchange": (C.c_int, [C.POINTER(SvgfParams), C.POINTER(C.c_int * 2)]),
+    "rmd_svgf_frame_iteration_reach": (C.c_int, [C.POINTER(SvgfParams), C.POINTER(C.c_int * 8)]),
+    "rmd_svgf_frame_iteration_plane": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.POINTER(_P)]),
     "rmd_svgf_frame_reach": (C.c_int, [C.POINTER(SvgfParams), C.POINTER(C.c_int * 4)]),
     "rmd_svgf_context_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
     "rmd_svgf_context_destroy": (None, [_P]),
     "rmd_svgf_context_reset_history": (C.c_int, [_P, _P]),
     "rmd_svgf_context_denoise": (C.c_int, [_P, C.POINTER(SvgfParams), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "rmd_svgf_context_denoise_part": (C.c_int, [_P, C.POINTER(SvgfParams), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int]),
+    "rmd_svgf_context_mid_plane": (C.c_int, [_P, C.POINTER(SvgfParams), C.POINTER(_P)]),
     "rmd_svgf_context_history": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "rmd_svgf_context_describe": (C.c_int, [_P, C.POINTER(SvgfFrameDesc)]),
     "rmd_strip_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rmd_strip_plan_make": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SvgfParams), C.POINTER(StripPlan)]),
     "rmd_halo_plan": (C.c_int, [C.POINTER(StripPlan), C.POINTER(HaloStep), C.c_int, C.POINTER(C.c_int)]),
     "rmd_halo_bytes": (C.c_size_t, [C.POINTER(StripPlan), C.c_int]),
+    "rmd_mid_halo_plan": (C.c_int, [C.POINTER(StripPlan), C.POINTER(HaloStep), C.c_int, C.POINTER(C.c_int)]),
+    "rmd_mid_exchange": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, _P, _P]),
+    "rmd_mid_exchange_all": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, C.POINTER(_P), C.POINTER(_P)]),
     "rmd_comm_available": (C.c_int, []),
     "rmd_comm_unique_id": (C.c_int, [_P]),
     "rmd_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),

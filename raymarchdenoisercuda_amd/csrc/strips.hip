@@ -105,19 +105,53 @@ int rmd_strip_rows(int height, int world, int rank, int* row0, int* row1)
 int rmd_strip_plan_make(int height, int world, int rank, const rmd_svgf_params* p, rmd_strip_plan* out)
 {
     if (!p || !out) return fail(RMD_E_NULL, "rmd_strip_plan_make: params/out is NULL");
-    int reach[4];
+    int reach[4], mid[2];
     if (int e = rmd_svgf_frame_reach(p, reach)) return e;
+    if (int e = rmd_svgf_frame_mid_exchange(p, mid)) return e;
     int row0, row1;
     if (int e = rmd_strip_rows(height, world, rank, &row0, &row1)) return e;
     if (world > 1 && height / world < reach[1])
         return fail(RMD_E_ROWS, "rmd_strip_plan_make: strips of %d rows are shorter than the history reach %d: use fewer ranks, "
                     "a taller frame or a smaller max_motion_rows", height / world, reach[1]);
-    const int r = reach[0] > reach[1] ? reach[0] : reach[1];
+    if (world > 1 && height / world < mid[1])
+        return fail(RMD_E_ROWS, "rmd_strip_plan_make: strips of %d rows are shorter than the %d rows of the mid-frame exchange: use fewer "
+                    "ranks or a later exchange_iteration", height / world, mid[1]);
+    int r = reach[0] > reach[1] ? reach[0] : reach[1];
+    if (mid[1] > r) r = mid[1];
     const int b0 = row0 - r > 0 ? row0 - r : 0, b1 = row1 + r < height ? row1 + r : height;
     out->height = height; out->world = world; out->rank = rank;
     out->row0 = row0; out->row1 = row1;
     out->buf_row0 = b0; out->buf_rows = b1 - b0;
     out->reach_in = reach[0]; out->reach_hist = reach[1]; out->have_color = reach[2]; out->have_moments = reach[3];
+    out->mid_iteration = mid[0]; out->mid_rows = mid[1];
+    return RMD_OK;
+}
+
+// The exchange INSIDE a frame (rmd_svgf_params.exchange_iteration): the mid_rows rows of iteration X's output beyond either
+// end of the strip come from the neighbour that computed them as its own rows.  plane index RMD_PLANE_MID.
+int rmd_mid_halo_plan(const rmd_strip_plan* plan, rmd_halo_step* steps, int max_steps, int* n_steps)
+{
+    if (!plan || !n_steps) return fail(RMD_E_NULL, "rmd_mid_halo_plan: plan/n_steps is NULL");
+    int n = 0;
+    auto push = [&](int kind, int lo, int hi, int peer) {
+        if (hi <= lo) return;
+        if (steps && n < max_steps) steps[n] = rmd_halo_step{ kind, RMD_PLANE_MID, lo, hi, peer };
+        ++n;
+    };
+    auto clamp = [&](int v) { return v < 0 ? 0 : (v > plan->height ? plan->height : v); };
+    if (plan->world > 1 && plan->mid_iteration >= 0 && plan->mid_rows > 0) {
+        const int up = plan->rank - 1, down = plan->rank + 1, R = plan->mid_rows;
+        if (up >= 0) {
+            push(RMD_HALO_RECV, clamp(plan->row0 - R), plan->row0, up);
+            push(RMD_HALO_SEND, plan->row0, clamp(plan->row0 + R), up);
+        }
+        if (down < plan->world) {
+            push(RMD_HALO_RECV, plan->row1, clamp(plan->row1 + R), down);
+            push(RMD_HALO_SEND, clamp(plan->row1 - R), plan->row1, down);
+        }
+    }
+    *n_steps = n;
+    if (steps && n > max_steps) return fail(RMD_E_BUFFER, "rmd_mid_halo_plan: %d steps, room for %d", n, max_steps);
     return RMD_OK;
 }
 
@@ -223,12 +257,12 @@ int rmd_comm_destroy(rmd_comm* c)
 
 // One rank's part of an exchange: its steps, on its planes, inside an open group.
 static int post_steps(Rccl* r, ncclComm_t comm, const rmd_halo_step* steps, int n, int buf_row0, int buf_rows, int width,
-                      float* hist_color, float* hist_moments, hipStream_t stream)
+                      float* hist_color, float* hist_moments, hipStream_t stream, float* mid_plane = nullptr)
 {
     for (int i = 0; i < n; ++i) {
         const rmd_halo_step& s = steps[i];
-        float* plane = s.plane == 0 ? hist_color : hist_moments;
-        if (!plane) return fail(RMD_E_NULL, "rmd_halo_exchange: history plane %d is NULL", s.plane);
+        float* plane = s.plane == RMD_PLANE_MID ? mid_plane : (s.plane == 0 ? hist_color : hist_moments);
+        if (!plane) return fail(RMD_E_NULL, "rmd_halo_exchange: plane %d is NULL", s.plane);
         if (s.row_lo < buf_row0 || s.row_hi > buf_row0 + buf_rows || s.row_lo >= s.row_hi)
             return fail(RMD_E_ROWS, "rmd_halo_exchange: rows [%d,%d) outside the planes [%d,%d)", s.row_lo, s.row_hi, buf_row0, buf_row0 + buf_rows);
         float* p = plane + (size_t)(s.row_lo - buf_row0) * (size_t)width * 4u;
@@ -266,6 +300,53 @@ int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float*
     if (n == 0) return RMD_OK;
     if (c && c->world != plan->world) return fail(RMD_E_PARAM, "rmd_halo_exchange: communicator of %d ranks, plan of %d", c->world, plan->world);
     return rmd_halo_exchange_steps(c, 0, st, n, plan->buf_row0, plan->buf_rows, width, hist_color, hist_moments, stream);
+}
+
+int rmd_mid_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* mid_plane, void* stream)
+{
+    if (!plan) return fail(RMD_E_NULL, "rmd_mid_exchange: plan is NULL");
+    if (c && (int)c->comms.size() != 1) return fail(RMD_E_PARAM, "rmd_mid_exchange: one communicator per process expected; use rmd_mid_exchange_all");
+    rmd_halo_step st[RMD_HALO_MAX_STEPS];
+    int n = 0;
+    if (int e = rmd_mid_halo_plan(plan, st, RMD_HALO_MAX_STEPS, &n)) return e;
+    if (n == 0) return RMD_OK;
+    if (!c) return fail(RMD_E_NULL, "rmd_mid_exchange: communicator is NULL");
+    if (c->world != plan->world) return fail(RMD_E_PARAM, "rmd_mid_exchange: communicator of %d ranks, plan of %d", c->world, plan->world);
+    if (!mid_plane || width <= 0) return fail(RMD_E_NULL, "rmd_mid_exchange: plane is NULL or width <= 0");
+    Rccl* r = rccl();
+    if (!r) return fail(RMD_E_COMM, "rmd_mid_exchange: librccl.so not found");
+    RMD_NCCL(r, r->GroupStart());
+    const int e = post_steps(r, c->comms[0], st, n, plan->buf_row0, plan->buf_rows, width, nullptr, nullptr, as_stream(stream), mid_plane);
+    const int g = r->GroupEnd();
+    if (e) return e;
+    if (g != kNcclSuccess) return nccl_fail(r, g, "ncclGroupEnd");
+    return RMD_OK;
+}
+
+int rmd_mid_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* mid_planes, void* const* streams)
+{
+    if (!c || !plans || !mid_planes) return fail(RMD_E_NULL, "rmd_mid_exchange_all: NULL argument");
+    if ((int)c->comms.size() != c->world) return fail(RMD_E_PARAM, "rmd_mid_exchange_all: needs a communicator from rmd_comm_create_all");
+    Rccl* r = rccl();
+    if (!r) return fail(RMD_E_COMM, "rmd_mid_exchange_all: librccl.so not found");
+    int prev = 0;
+    RMD_HIP(hipGetDevice(&prev));
+    RMD_NCCL(r, r->GroupStart());
+    int err = RMD_OK;
+    for (int k = 0; k < c->world && !err; ++k) {
+        rmd_halo_step st[RMD_HALO_MAX_STEPS];
+        int n = 0;
+        err = rmd_mid_halo_plan(&plans[k], st, RMD_HALO_MAX_STEPS, &n);
+        if (err) break;
+        if (hipSetDevice(c->devices[k]) != hipSuccess) { err = fail(RMD_E_PARAM, "rmd_mid_exchange_all: hipSetDevice(%d) failed", c->devices[k]); break; }
+        err = post_steps(r, c->comms[k], st, n, plans[k].buf_row0, plans[k].buf_rows, width, nullptr, nullptr,
+                         as_stream(streams ? streams[k] : nullptr), mid_planes[k]);
+    }
+    const int g = r->GroupEnd();
+    (void)hipSetDevice(prev);
+    if (err) return err;
+    if (g != kNcclSuccess) return nccl_fail(r, g, "ncclGroupEnd");
+    return RMD_OK;
 }
 
 int rmd_halo_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* hist_color, float* const* hist_moments,

@@ -15,12 +15,19 @@
 namespace rmd {
 
 struct Reach {
-    int atrous[16];   // rows above/below [row0,row1) on which iteration i's OUTPUT is needed
+    int atrous[16];   // rows above/below [row0,row1) on which this call COMPUTES iteration i's output
+    int need[16];     // rows above/below [row0,row1) on which iteration i's output is NEEDED by the later passes
     int v, t;         // same for the V and T outputs
     int input;        // current-frame input planes (color, nd, motion)
     int history;      // history planes
+    int mid;          // p->exchange_iteration, or -1: the iteration whose output is completed by a neighbour exchange
+    int mid_rows;     // need[mid]: rows per side that travel
 };
 
+// Redundant rows instead of per-pass halo exchanges: iteration i's output is needed on
+// need[i] = need[i+1] + 2*2^(i+1) rows beyond the strip, and a strip computes exactly that.  With ONE neighbour
+// exchange inside the frame (rmd_svgf_params.exchange_iteration = X, SURVEY §8e "Halo sizes"), iteration X is computed
+// on the strip's own rows only, its need[X] halo rows arrive from rank +-1, and everything in front of X shrinks with it.
 static int compute_reach(const rmd_svgf_params* p, Reach& r)
 {
     if (!p) return fail(RMD_E_NULL, "svgf params is NULL");
@@ -28,8 +35,18 @@ static int compute_reach(const rmd_svgf_params* p, Reach& r)
     if (p->hist_iteration < 0 || p->hist_iteration >= p->iterations)
         return fail(RMD_E_PARAM, "hist_iteration %d outside [0,%d)", p->hist_iteration, p->iterations);
     const int n = p->iterations;
-    r.atrous[n - 1] = 0;
-    for (int i = n - 2; i >= 0; --i) r.atrous[i] = r.atrous[i + 1] + 2 * (1 << (i + 1));
+    if (p->exchange_iteration < -1 || p->exchange_iteration > n - 2)
+        return fail(RMD_E_PARAM, "exchange_iteration %d outside [-1,%d] (the last iteration has nothing behind it to exchange for)",
+                    p->exchange_iteration, n - 2);
+    r.mid = p->exchange_iteration;
+    r.need[n - 1] = 0;
+    for (int i = n - 2; i >= 0; --i) r.need[i] = r.need[i + 1] + 2 * (1 << (i + 1));
+    for (int i = n - 1; i >= 0; --i) {
+        if (i > r.mid || r.mid < 0) r.atrous[i] = r.need[i];
+        else if (i == r.mid)        r.atrous[i] = 0;
+        else                        r.atrous[i] = r.atrous[i + 1] + 2 * (1 << (i + 1));
+    }
+    r.mid_rows = r.mid >= 0 ? r.need[r.mid] : 0;
     r.v = r.atrous[0] + 2;                                  // iteration 0 taps +-2 rows
     r.t = r.v + (p->var_radius > 1 ? p->var_radius : 1);    // V taps +-var_radius rows of T's output
     r.input = r.t + 1;                                      // depth gradient reads nd(y+1)
@@ -66,7 +83,7 @@ void rmd_svgf_default_params(rmd_svgf_params* p)
     p->var_h_threshold = 4; p->var_radius = 3;
     p->sigma_n = 128.0f; p->sigma_z = 1.0f; p->sigma_l = 4.0f;
     p->iterations = 5; p->hist_iteration = 0; p->atrous_variant = 0;
-    p->tv_workgroups = 0; p->atrous_cus = 0;
+    p->tv_workgroups = 0; p->atrous_cus = 0; p->exchange_iteration = -1;
 }
 
 int rmd_svgf_frame_reach(const rmd_svgf_params* p, int reach[4])
@@ -76,8 +93,29 @@ int rmd_svgf_frame_reach(const rmd_svgf_params* p, int reach[4])
     if (int e = compute_reach(p, r)) return e;
     reach[0] = r.input;
     reach[1] = r.history;
-    reach[2] = r.atrous[p->hist_iteration];
+    // hist_color_out rows a rank holds after the frame: what it computed, or -- when the history iteration is the
+    // exchanged one -- its own rows plus the halo it received
+    reach[2] = p->hist_iteration == r.mid ? r.mid_rows : r.atrous[p->hist_iteration];
     reach[3] = r.t;
+    return RMD_OK;
+}
+
+int rmd_svgf_frame_iteration_reach(const rmd_svgf_params* p, int reach[8])
+{
+    if (!reach) return fail(RMD_E_NULL, "rmd_svgf_frame_iteration_reach: reach is NULL");
+    Reach r;
+    if (int e = compute_reach(p, r)) return e;
+    for (int i = 0; i < 8; ++i) reach[i] = i < p->iterations ? r.atrous[i] : 0;
+    return RMD_OK;
+}
+
+int rmd_svgf_frame_mid_exchange(const rmd_svgf_params* p, int mid[2])
+{
+    if (!mid) return fail(RMD_E_NULL, "rmd_svgf_frame_mid_exchange: mid is NULL");
+    Reach r;
+    if (int e = compute_reach(p, r)) return e;
+    mid[0] = r.mid;
+    mid[1] = r.mid_rows;
     return RMD_OK;
 }
 
@@ -116,31 +154,87 @@ int rmd_svgf_frame_tv(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, in
     return launch_variance(f, p, v0, v1, stream, fuse, sparse);
 }
 
+// plane routing of the a-trous iterations (Appendix A.A.4): in / out plane of iteration i
+static void atrous_route(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int i, const float** in, float** out)
+{
+    const int n = p->iterations;
+    const float* src = f->v_color;
+    int pp = 0;
+    for (int k = 0; k <= i; ++k) {
+        float* dst;
+        if (k == n - 1) dst = f->out_color;
+        else if (k == p->hist_iteration) dst = f->hist_color_out;
+        else { dst = f->ping[pp]; pp ^= 1; }
+        if (k == i) { *in = src; *out = dst; }
+        src = dst;
+    }
+}
+
+int rmd_svgf_frame_iteration_plane(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration, float** plane)
+{
+    if (!f || !plane) return fail(RMD_E_NULL, "rmd_svgf_frame_iteration_plane: NULL argument");
+    Reach r;
+    if (int e = compute_reach(p, r)) return e;
+    if (iteration < 0 || iteration >= p->iterations) return fail(RMD_E_PARAM, "rmd_svgf_frame_iteration_plane: iteration %d", iteration);
+    const float* in;
+    atrous_route(f, p, iteration, &in, plane);
+    return RMD_OK;
+}
+
 int rmd_svgf_frame_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
                           void* history_ready_event)
 {
+    return rmd_svgf_frame_atrous_part(f, p, row0, row1, stream, history_ready_event, RMD_ATROUS_ALL);
+}
+
+int rmd_svgf_frame_atrous_part(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
+                               void* history_ready_event, int part)
+{
     Reach r;
     if (int e = check_frame_call(f, p, row0, row1, r)) return e;
+    if (part < RMD_ATROUS_ALL || part > RMD_ATROUS_TAIL) return fail(RMD_E_PARAM, "rmd_svgf_frame_atrous_part: part %d", part);
+    if (part != RMD_ATROUS_ALL && r.mid < 0)
+        return fail(RMD_E_PARAM, "rmd_svgf_frame_atrous_part: parts need rmd_svgf_params.exchange_iteration >= 0");
     const int H = f->height;
     const int n = p->iterations;
-    const float* in = f->v_color;
-    int pp = 0;
     for (int i = 0; i < n; ++i) {
+        const float* in;
         float* out;
-        if (i == n - 1) out = f->out_color;
-        else if (i == p->hist_iteration) out = f->hist_color_out;
-        else { out = f->ping[pp]; pp ^= 1; }
+        atrous_route(f, p, i, &in, &out);
         const int a0 = clampi(row0 - r.atrous[i], 0, H), a1 = clampi(row1 + r.atrous[i], 0, H);
-        if (int e = rmd_svgf_atrous(f, p, i, in, out, a0, a1, stream)) return e;
+        // Rows of iteration mid+1 that tap nothing of the exchanged halo: at least 2 steps inside the strip on every side that
+        // HAS rows beyond it (a strip edge that is the frame edge has no halo).  They can run while the halo travels.
+        int lo = a0, hi = a1;
+        if (r.mid >= 0 && i == r.mid + 1) {
+            const int reach_i = 2 * (1 << i);
+            if (row0 > 0) lo = clampi(row0 + reach_i, a0, a1);
+            if (row1 < H) hi = clampi(row1 - reach_i, lo, a1);
+        }
+        // which row ranges of this iteration the requested part runs
+        int ranges[2][2], nr = 0;
+        const bool head = r.mid < 0 || i <= r.mid;
+        if (part == RMD_ATROUS_ALL || (part == RMD_ATROUS_HEAD && head) || (part == RMD_ATROUS_TAIL && !head && i != r.mid + 1)) {
+            ranges[nr][0] = a0; ranges[nr][1] = a1; ++nr;
+        } else if (part == RMD_ATROUS_INTERIOR && i == r.mid + 1) {
+            if (hi > lo) { ranges[nr][0] = lo; ranges[nr][1] = hi; ++nr; }
+        } else if (part == RMD_ATROUS_TAIL && i == r.mid + 1) {
+            if (hi > lo) {
+                if (lo > a0) { ranges[nr][0] = a0; ranges[nr][1] = lo; ++nr; }
+                if (a1 > hi) { ranges[nr][0] = hi; ranges[nr][1] = a1; ++nr; }
+            } else { ranges[nr][0] = a0; ranges[nr][1] = a1; ++nr; }      // strip too short for an interior: everything waits
+        }
+        for (int q = 0; q < nr; ++q)
+            if (int e = rmd_svgf_atrous(f, p, i, in, out, ranges[q][0], ranges[q][1], stream)) return e;
+        if (nr == 0) continue;
         if (i == n - 1 && i == p->hist_iteration && f->hist_color_out != out) {
             const size_t off = (size_t)(a0 - f->buf_row0) * f->width * 4;
             RMD_HIP(hipMemcpyAsync(f->hist_color_out + off, out + off, (size_t)(a1 - a0) * f->width * 16,
                                    hipMemcpyDeviceToDevice, as_stream(stream)));
         }
-        // next frame's history (hist_color_out, and t_moments since T ran before) is complete here
-        if (i == p->hist_iteration && history_ready_event)
+        // next frame's history (hist_color_out, and t_moments since T ran before) is complete here -- up to the rows a
+        // mid-frame exchange still has to deliver when hist_iteration IS the exchanged iteration
+        if (i == p->hist_iteration && history_ready_event && part != RMD_ATROUS_INTERIOR)
             RMD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(history_ready_event), as_stream(stream)));
-        in = out;
     }
     return RMD_OK;
 }
@@ -220,23 +314,57 @@ int rmd_svgf_context_describe(rmd_svgf_context* c, rmd_svgf_frame_desc* f)
     return RMD_OK;
 }
 
-int rmd_svgf_context_denoise(rmd_svgf_context* c, const rmd_svgf_params* p, const float* color, const float* nd,
-                             const float* motion, const float* prev_nd, float* out, int row0, int row1, void* stream)
+static int context_frame_desc(rmd_svgf_context* c, const float* color, const float* nd, const float* motion, const float* prev_nd,
+                              float* out, rmd_svgf_frame_desc* f)
 {
     if (!c) return fail(RMD_E_NULL, "rmd_svgf_context_denoise: ctx is NULL");
     if (!color || !nd || !motion || !out) return fail(RMD_E_NULL, "rmd_svgf_context_denoise: a required plane is NULL");
-    rmd_svgf_frame_desc f = {};
-    if (int e = rmd_svgf_context_describe(c, &f)) return e;
-    f.color = color; f.nd = nd; f.motion = motion;
+    *f = rmd_svgf_frame_desc{};
+    if (int e = rmd_svgf_context_describe(c, f)) return e;
+    f->color = color; f->nd = nd; f->motion = motion;
     const bool use_hist = c->has_history && prev_nd != nullptr;
-    f.prev_nd = use_hist ? prev_nd : nullptr;
-    if (!use_hist) { f.hist_color = nullptr; f.hist_moments = nullptr; }
-    f.out_color = out;
-    f.t_debug = nullptr; f.stats = nullptr;
+    f->prev_nd = use_hist ? prev_nd : nullptr;
+    if (!use_hist) { f->hist_color = nullptr; f->hist_moments = nullptr; }
+    f->out_color = out;
+    f->t_debug = nullptr; f->stats = nullptr;
+    return RMD_OK;
+}
+
+int rmd_svgf_context_denoise(rmd_svgf_context* c, const rmd_svgf_params* p, const float* color, const float* nd,
+                             const float* motion, const float* prev_nd, float* out, int row0, int row1, void* stream)
+{
+    rmd_svgf_frame_desc f;
+    if (int e = context_frame_desc(c, color, nd, motion, prev_nd, out, &f)) return e;
     if (int e = rmd_svgf_frame(&f, p, row0, row1, stream)) return e;
     c->cur ^= 1;            // this frame's t_moments / hist_color_out become the history
     c->has_history = true;
     return RMD_OK;
+}
+
+int rmd_svgf_context_denoise_part(rmd_svgf_context* c, const rmd_svgf_params* p, const float* color, const float* nd,
+                                  const float* motion, const float* prev_nd, float* out, int row0, int row1, void* stream, int part)
+{
+    rmd_svgf_frame_desc f;
+    if (int e = context_frame_desc(c, color, nd, motion, prev_nd, out, &f)) return e;
+    if (part == RMD_ATROUS_HEAD)
+        if (int e = rmd_svgf_frame_tv(&f, p, row0, row1, stream)) return e;
+    if (int e = rmd_svgf_frame_atrous_part(&f, p, row0, row1, stream, nullptr, part)) return e;
+    if (part == RMD_ATROUS_TAIL || part == RMD_ATROUS_ALL) {
+        c->cur ^= 1;
+        c->has_history = true;
+    }
+    return RMD_OK;
+}
+
+int rmd_svgf_context_mid_plane(rmd_svgf_context* c, const rmd_svgf_params* p, float** plane)
+{
+    if (!c || !plane) return fail(RMD_E_NULL, "rmd_svgf_context_mid_plane: NULL argument");
+    int mid[2];
+    if (int e = rmd_svgf_frame_mid_exchange(p, mid)) return e;
+    if (mid[0] < 0) return fail(RMD_E_PARAM, "rmd_svgf_context_mid_plane: exchange_iteration is -1");
+    rmd_svgf_frame_desc f = {};
+    if (int e = rmd_svgf_context_describe(c, &f)) return e;
+    return rmd_svgf_frame_iteration_plane(&f, p, mid[0], plane);
 }
 
 int rmd_svgf_context_history(rmd_svgf_context* c, float** hist_color, float** hist_moments)

@@ -322,40 +322,47 @@ TEST(SVGF_STRIPS)
             out.copyTo(want[f]);
         }
     }
-    NodeDenoiser node(W, H, p, devices);
-    std::vector<std::vector<CudaVector<float>>> color(world), nd(world), motion(world);
-    std::vector<CudaVector<float>> out;
-    for (int k = 0; k < world; ++k) {
-        const StripPlan& pl = node.ranks[k].plan;
-        rmdCheck(rmd_set_device(devices[k]), "set device");
-        const size_t m = (size_t)W * pl.buf_rows;
-        out.emplace_back(4 * m);
-        for (int f = 0; f < frames; ++f) {
-            color[k].emplace_back(4 * m); nd[k].emplace_back(4 * m); motion[k].emplace_back(2 * m);
-            rmd_synth_desc d = { W, H, pl.buf_row0, pl.buf_rows, 1234u, f, 1.25f, -0.5f };
-            rmdCheck(rmd_synth_gbuffer(&d, color[k][f].data(), nd[k][f].data(), motion[k][f].data(), nullptr, nullptr), "synth strip");
-        }
-        expect(pl.haloSteps().size() == (k == 0 || k == world - 1 ? 4u : 8u), "a border rank exchanges with one neighbour, an inner rank with two");
-    }
-    rmdCheck(rmd_device_sync(), "sync");
     size_t differing = 0;
-    for (int f = 0; f < frames; ++f) {
-        std::vector<const float*> c(world), g(world), m(world), pn(world);
-        std::vector<float*> o(world);
-        for (int k = 0; k < world; ++k) {
-            c[k] = color[k][f].data(); g[k] = nd[k][f].data(); m[k] = motion[k][f].data();
-            pn[k] = f ? nd[k][f - 1].data() : nullptr; o[k] = out[k].data();
-        }
-        node.denoise(c, g, m, pn, o);
-        node.synchronize();
+    // redundant rows only, and one neighbour exchange inside the frame (A3's 32 halo rows; T, V, A0..A2 on 32 fewer rows per side)
+    for (int exchange : { -1, 3 }) {
+        SvgfParams ps = p;
+        ps.exchange_iteration = exchange;
+        NodeDenoiser node(W, H, ps, devices);
+        std::vector<std::vector<CudaVector<float>>> color(world), nd(world), motion(world);
+        std::vector<CudaVector<float>> out;
         for (int k = 0; k < world; ++k) {
             const StripPlan& pl = node.ranks[k].plan;
             rmdCheck(rmd_set_device(devices[k]), "set device");
-            CpuVector<float> got;
-            out[k].copyTo(got);
-            for (int y = pl.row0; y < pl.row1; ++y)
-                differing += memcmp(&got[(size_t)(y - pl.buf_row0) * W * 4], &want[f][(size_t)y * W * 4], (size_t)W * 16) != 0;
+            const size_t m = (size_t)W * pl.buf_rows;
+            out.emplace_back(4 * m);
+            for (int f = 0; f < frames; ++f) {
+                color[k].emplace_back(4 * m); nd[k].emplace_back(4 * m); motion[k].emplace_back(2 * m);
+                rmd_synth_desc d = { W, H, pl.buf_row0, pl.buf_rows, 1234u, f, 1.25f, -0.5f };
+                rmdCheck(rmd_synth_gbuffer(&d, color[k][f].data(), nd[k][f].data(), motion[k][f].data(), nullptr, nullptr), "synth strip");
+            }
+            expect(pl.haloSteps().size() == (k == 0 || k == world - 1 ? 4u : 8u), "a border rank exchanges with one neighbour, an inner rank with two");
+            expect(pl.midSteps().size() == (exchange < 0 ? 0u : (k == 0 || k == world - 1 ? 2u : 4u)), "the mid-frame exchange: one send and one receive per neighbour");
         }
+        rmdCheck(rmd_device_sync(), "sync");
+        for (int f = 0; f < frames; ++f) {
+            std::vector<const float*> c(world), g(world), m(world), pn(world);
+            std::vector<float*> o(world);
+            for (int k = 0; k < world; ++k) {
+                c[k] = color[k][f].data(); g[k] = nd[k][f].data(); m[k] = motion[k][f].data();
+                pn[k] = f ? nd[k][f - 1].data() : nullptr; o[k] = out[k].data();
+            }
+            node.denoise(c, g, m, pn, o);
+            node.synchronize();
+            for (int k = 0; k < world; ++k) {
+                const StripPlan& pl = node.ranks[k].plan;
+                rmdCheck(rmd_set_device(devices[k]), "set device");
+                CpuVector<float> got;
+                out[k].copyTo(got);
+                for (int y = pl.row0; y < pl.row1; ++y)
+                    differing += memcmp(&got[(size_t)(y - pl.buf_row0) * W * 4], &want[f][(size_t)y * W * 4], (size_t)W * 16) != 0;
+            }
+        }
+        printf("exchange_iteration %d: buffers of %d rows per inner rank\n", exchange, node.ranks[1].plan.buf_rows);
     }
     rmdCheck(rmd_set_device(0), "set device");
     printf("%d frames x %d strips: %zu rows differ from the unsharded frame\n", frames, world, differing);

@@ -32,6 +32,8 @@ class StripPlan:
     reach_hist: int    # history rows read beyond the strip
     have_color: int    # hist_color rows this rank produces itself beyond the strip
     have_moments: int  # hist_moments rows this rank produces itself beyond the strip
+    mid_iteration: int = -1   # a-trous iteration whose output crosses ranks INSIDE a frame (rmd_svgf_params.exchange_iteration)
+    mid_rows: int = 0         # rows per side that travel in that exchange
 
 
 def strip_rows(height, world, rank):
@@ -40,18 +42,24 @@ def strip_rows(height, world, rank):
     return row0, row0 + base + (1 if rank < rem else 0)
 
 
-def make_plan(height, world, rank, reach) -> StripPlan:
-    """reach = svgf.frame_reach(params) = (reach_in, reach_hist, have_color, have_moments)."""
+def make_plan(height, world, rank, reach, mid=(-1, 0)) -> StripPlan:
+    """reach = svgf.frame_reach(params) = (reach_in, reach_hist, have_color, have_moments);
+    mid = svgf.frame_mid_exchange(params) = (exchange iteration or -1, rows per side)."""
     reach_in, reach_hist, have_color, have_moments = reach
+    mid_iteration, mid_rows = mid
     row0, row1 = strip_rows(height, world, rank)
     if world > 1:
         smallest = height // world
         if smallest < reach_hist:
             raise ValueError(f"strips of {smallest} rows are shorter than the history reach {reach_hist}: "
                              "use fewer ranks, a taller frame or a smaller max_motion_rows")
-    reach = max(reach_in, reach_hist)
+        if smallest < mid_rows:
+            raise ValueError(f"strips of {smallest} rows are shorter than the {mid_rows} rows of the mid-frame exchange: "
+                             "use fewer ranks or a later exchange_iteration")
+    reach = max(reach_in, reach_hist, mid_rows)
     b0, b1 = max(0, row0 - reach), min(height, row1 + reach)
-    return StripPlan(height, world, rank, row0, row1, b0, b1 - b0, reach_in, reach_hist, have_color, have_moments)
+    return StripPlan(height, world, rank, row0, row1, b0, b1 - b0, reach_in, reach_hist, have_color, have_moments,
+                     mid_iteration, mid_rows)
 
 
 def _rows(plane, plan, lo, hi):
@@ -93,6 +101,23 @@ def halo_plan(plan: StripPlan):
     return steps
 
 
+def mid_halo_plan(plan: StripPlan):
+    """The exchange INSIDE a frame (rmd_svgf_params.exchange_iteration = X): iteration X is computed on the strip's own
+    rows only; the mid_rows rows of its output beyond either end of the strip come from the neighbour that computed
+    them as ITS own rows.  Same step format as halo_plan, plane "mid"."""
+    steps = []
+    if plan.world == 1 or plan.mid_iteration < 0 or plan.mid_rows <= 0:
+        return steps
+    up, down, R, H = plan.rank - 1, plan.rank + 1, plan.mid_rows, plan.height
+    if up >= 0:
+        steps.append(("recv", "mid", max(0, plan.row0 - R), plan.row0, up))
+        steps.append(("send", "mid", plan.row0, min(H, plan.row0 + R), up))
+    if down < plan.world:
+        steps.append(("recv", "mid", plan.row1, min(H, plan.row1 + R), down))
+        steps.append(("send", "mid", max(0, plan.row1 - R), plan.row1, down))
+    return [s for s in steps if s[3] > s[2]]
+
+
 def halo_ops(plan: StripPlan, hist_color, hist_moments, group=None):
     """torch.distributed P2P ops for halo_plan(plan) on this rank's history planes."""
     planes = {"color": hist_color, "moments": hist_moments}
@@ -109,13 +134,23 @@ def exchange_history_halo(plan: StripPlan, hist_color, hist_moments, group=None)
     With RCCL ("nccl") the device rows travel directly over xGMI.  With gloo and device planes (the
     one-GPU rehearsal of the multi-rank path) the rows are staged through host memory.
     """
-    steps = halo_plan(plan)
+    return _exchange(plan, halo_plan(plan), {"color": hist_color, "moments": hist_moments}, group)
+
+
+def exchange_mid_halo(plan: StripPlan, mid_plane, group=None):
+    """The mid-frame exchange of mid_halo_plan(plan) on the output plane of iteration plan.mid_iteration."""
+    return _exchange(plan, mid_halo_plan(plan), {"mid": mid_plane}, group)
+
+
+def _exchange(plan, steps, planes, group):
     if not steps:
         return 0
-    planes = {"color": hist_color, "moments": hist_moments}
-    staged = hist_color.is_cuda and dist.get_backend(group) == "gloo"
+    first = next(iter(planes.values()))
+    staged = first.is_cuda and dist.get_backend(group) == "gloo"
     if not staged:
-        for req in dist.batch_isend_irecv(halo_ops(plan, hist_color, hist_moments, group)):
+        ops = [dist.P2POp(dist.irecv if kind == "recv" else dist.isend, _rows(planes[name], plan, lo, hi), peer, group)
+               for kind, name, lo, hi, peer in steps]
+        for req in dist.batch_isend_irecv(ops):
             req.wait()
         return len(steps)
     ops, landing = [], []
@@ -134,8 +169,13 @@ def exchange_history_halo(plan: StripPlan, hist_color, hist_moments, group=None)
     return len(steps)
 
 
+def mid_halo_bytes(plan: StripPlan, width):
+    """Bytes this rank receives in the mid-frame exchange."""
+    return sum((hi - lo) * width * 16 for kind, _, lo, hi, _ in mid_halo_plan(plan) if kind == "recv")
+
+
 def halo_bytes(plan: StripPlan, width):
-    """Bytes this rank receives per frame (for reporting)."""
+    """History bytes this rank receives per frame (for reporting)."""
     total = 0
     for have in (plan.have_color, plan.have_moments):
         rows = max(0, plan.reach_hist - have)
@@ -147,11 +187,16 @@ def halo_bytes(plan: StripPlan, width):
 
 
 class ShardedDenoiser:
-    """Per-rank driver: strip plan + SvgfDenoiser + the per-frame history halo exchange.
+    """Per-rank driver: strip plan + SvgfDenoiser + the neighbour exchanges of a frame.
 
-    The halo of frame k's history is completed lazily, right before frame k+1's temporal pass and
-    on the stream that pass runs on; with pipelined=True that is the second stream, so the exchange
-    (like T and V) runs underneath frame k's remaining a-trous iterations.
+    Serial frames (the default): the 7 launches of a frame run on one stream; the exchanges run on a second one,
+    ordered by events, underneath the a-trous iterations --
+      * next frame's HISTORY halo right after the history iteration (A_0) has been queued, awaited in front of the
+        next frame's temporal pass;
+      * with params.exchange_iteration = X >= 0, the MID-FRAME halo of iteration X's output right after X has been
+        queued; iteration X+1 meanwhile runs on its interior rows and takes its boundary rows once the halo is in.
+    pipelined=True is the older two-stream form (T+V of frame k+1 beside the a-trous iterations of frame k; the history
+    halo completed lazily on the T+V stream); it does not support exchange_iteration.
     """
 
     def __init__(self, width, height, params=None, device="cuda", group=None, rank=None, world=None, pipelined=False):
@@ -161,29 +206,81 @@ class ShardedDenoiser:
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if dist.is_initialized() else 0)
         self.params = params if params is not None else svgf.default_params()
-        self.plan = make_plan(height, self.world, self.rank, svgf.frame_reach(self.params))
+        self.plan = make_plan(height, self.world, self.rank, svgf.frame_reach(self.params), svgf.frame_mid_exchange(self.params))
         self.width, self.height = width, height
         self.den = svgf.SvgfDenoiser(width, height, self.plan.buf_row0, self.plan.buf_rows, self.params, device,
                                      pipelined=pipelined)
         self.exchange = self.world > 1 and dist.is_initialized()
+        self.pipelined = pipelined
         self._halo_pending = False
+        self._hist_done = self._mid_done = None
+        if self.exchange and not pipelined and torch.device(device).type == "cuda":
+            self.comm_stream = torch.cuda.Stream(device=device)
+            self._hist_done, self._mid_done = torch.cuda.Event(), torch.cuda.Event()
+        else:
+            self.comm_stream = None           # CPU planes (gloo tests): the exchanges run inline
 
     def synth(self, frame_index, out=None, **kw):
         return self.svgf.synth_gbuffer(self.width, self.height, frame_index, self.plan.buf_row0, self.plan.buf_rows,
                                        out=out, **kw)
 
+    # ---- pipelined form: the history halo lazily, on the stream T runs on
     def _complete_halo(self):
         if self._halo_pending:
             hc, hm = self.den.history()
             exchange_history_halo(self.plan, hc, hm, self.group)
             self._halo_pending = False
 
+    # ---- serial form: hooks of SvgfDenoiser.denoise
+    def before_tv(self):
+        if self._halo_pending and self._hist_done is not None:
+            torch.cuda.current_stream().wait_event(self._hist_done)
+        self._halo_pending = False
+
+    def _on_comm_stream(self, after_event, fn, done):
+        from ._lib import check, lib
+        check(lib.rmd_stream_wait_event(self.comm_stream.cuda_stream, after_event))
+        with torch.cuda.stream(self.comm_stream):
+            fn()
+            done.record(self.comm_stream)
+
+    def hist_ready(self, event):
+        """Next frame's history planes are complete behind `event`: exchange their halo rows now, beside the remaining
+        a-trous iterations."""
+        den = self.den
+        hc, hm = den.hist_color[den.cur ^ 1], den.hist_moments[den.cur ^ 1]      # what the NEXT frame reads
+        if self.comm_stream is None:
+            exchange_history_halo(self.plan, hc, hm, self.group)
+        else:
+            self._on_comm_stream(event, lambda: exchange_history_halo(self.plan, hc, hm, self.group), self._hist_done)
+        self._halo_pending = True
+
+    def mid_ready(self, plane):
+        if self.comm_stream is None:
+            exchange_mid_halo(self.plan, plane, self.group)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(ev)
+            exchange_mid_halo(self.plan, plane, self.group)
+            self._mid_done.record(self.comm_stream)
+
+    def mid_wait(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_event(self._mid_done)
+
     def denoise(self, color, nd, motion, out=None):
         """Strip rows [row0,row1) of `out` (valid after synchronize())."""
-        out = self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1,
-                               before_tv=self._complete_halo if self.exchange else None)
-        self._halo_pending = self.exchange
-        return out
+        if not self.exchange:
+            return self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1)
+        if self.pipelined:
+            out = self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1, before_tv=self._complete_halo)
+            self._halo_pending = True
+            return out
+        return self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1, before_tv=self.before_tv, hooks=self)
 
     def synchronize(self):
         self.den.synchronize()
+        if self.comm_stream is not None:
+            self.comm_stream.synchronize()

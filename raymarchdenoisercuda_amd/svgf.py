@@ -31,6 +31,23 @@ def frame_reach(params: SvgfParams):
     return tuple(int(v) for v in r)
 
 
+def frame_mid_exchange(params: SvgfParams):
+    """(exchange iteration or -1, rows per side that travel) of rmd_svgf_params.exchange_iteration."""
+    r = (C.c_int * 2)()
+    check(lib.rmd_svgf_frame_mid_exchange(C.byref(params), C.byref(r)))
+    return int(r[0]), int(r[1])
+
+
+def frame_iteration_reach(params: SvgfParams):
+    """Rows above/below its strip on which a rank computes each a-trous iteration (rmd_svgf_frame_iteration_reach)."""
+    r = (C.c_int * 8)()
+    check(lib.rmd_svgf_frame_iteration_reach(C.byref(params), C.byref(r)))
+    return [int(r[i]) for i in range(params.iterations)]
+
+
+ATROUS_ALL, ATROUS_HEAD, ATROUS_INTERIOR, ATROUS_TAIL = 0, 1, 2, 3      # include/rmd_api.h RMD_ATROUS_*
+
+
 def _ptr(t, name, rows, width, channels, dtype=torch.float32):
     if t is None:
         return None
@@ -164,23 +181,23 @@ class SvgfDenoiser:
         self.has_history = False
         self.prev_nd = None
         self.pipelined = pipelined
+        self._ev_hist = C.c_void_p()
+        check(lib.rmd_event_create(C.byref(self._ev_hist)))
         if pipelined:
             # The a-trous stream is the high-priority queue (measured: no effect on how the dispatcher
             # arbitrates between T's pending workgroups and a new a-trous launch; kept as the intent).
             self.stream_a = torch.cuda.Stream(device=device, priority=-1)       # a-trous iterations
             self.stream_b = torch.cuda.Stream(device=device, priority=0)        # T + V (+ the history halo exchange)
-            self._ev_hist, self._ev_tv = C.c_void_p(), C.c_void_p()
-            check(lib.rmd_event_create(C.byref(self._ev_hist)))
+            self._ev_tv = C.c_void_p()
             check(lib.rmd_event_create(C.byref(self._ev_tv)))
             self._hist_recorded = False
 
     def __del__(self):
         if sys.is_finalizing():            # the HIP runtime may already be gone: leave streams and events to the process exit
             return
-        if getattr(self, "pipelined", False):
-            for ev in (self._ev_hist, self._ev_tv):
-                if ev:
-                    lib.rmd_event_destroy(ev)
+        for ev in (getattr(self, "_ev_hist", None), getattr(self, "_ev_tv", None)):
+            if ev:
+                lib.rmd_event_destroy(ev)
 
     def reset_history(self):
         self.has_history = False
@@ -209,11 +226,30 @@ class SvgfDenoiser:
             v_color=self.v_color, hist_color_out=self.hist_color[self.cur ^ 1],
             ping=(self.ping[0], self.ping[1]), out_color=out, stats=self.stats, tile_flags=self.tile_flags)
 
-    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None):
+    def iteration_plane(self, iteration, out=None):
+        """The plane a-trous iteration `iteration` of the NEXT denoise call writes (rmd_svgf_frame's routing)."""
+        n, pp = self.params.iterations, 0
+        for k in range(iteration + 1):
+            if k == n - 1:
+                dst = out
+            elif k == self.params.hist_iteration:
+                dst = self.hist_color[self.cur ^ 1]
+            else:
+                dst, pp = self.ping[pp], pp ^ 1
+        return dst
+
+    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None, hooks=None):
         """One frame.  `nd` is borrowed until the next call (it becomes prev_nd).  `before_tv` is
         called just before T is launched, on the stream T runs on (a row-strip deployment completes
         its history halo there).  Serial form: runs on `stream` (default: torch's current stream).
-        Pipelined form: runs on two side streams; the inputs must stay untouched until synchronize()."""
+        Pipelined form: runs on two side streams; the inputs must stay untouched until synchronize().
+
+        `hooks` (serial form; a row-strip deployment, sharding.ShardedDenoiser) may have
+          hist_ready(event)  called on the host once the launches that complete next frame's history planes are queued;
+                             `event` (a hipEvent_t) is recorded behind them on the frame's stream
+          mid_ready(plane)   params.exchange_iteration = X >= 0: called after iterations 0..X are queued, with X's output plane;
+                             the hook starts the neighbour exchange of its halo rows on another stream
+          mid_wait()         called before the launches that read that halo (makes the frame's stream wait for it)."""
         if out is None:
             out = torch.empty_like(color)
         row0 = max(self.buf_row0, 0) if row0 is None else row0
@@ -224,8 +260,30 @@ class SvgfDenoiser:
                 before_tv()
             # the caller's CURRENT torch stream unless told otherwise (NULL would be unordered with a
             # `with torch.cuda.stream(s)` block around this call)
-            frame(d, self.params, row0, row1, torch.cuda.current_stream() if stream is None else stream)
+            s_ptr = _stream_ptr(torch.cuda.current_stream() if stream is None else stream)
+            mid = frame_mid_exchange(self.params)[0]
+            p = self.params
+            check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(p), row0, row1, s_ptr))
+            if mid < 0:
+                check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist))
+                if hooks is not None and hasattr(hooks, "hist_ready"):
+                    hooks.hist_ready(self._ev_hist)
+            else:
+                hist_in_head = p.hist_iteration <= mid
+                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist, ATROUS_HEAD))
+                if hooks is not None and hasattr(hooks, "mid_ready"):
+                    hooks.mid_ready(self.iteration_plane(mid, out))
+                if hist_in_head and hooks is not None and hasattr(hooks, "hist_ready"):
+                    hooks.hist_ready(self._ev_hist)
+                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist, ATROUS_INTERIOR))
+                if hooks is not None and hasattr(hooks, "mid_wait"):
+                    hooks.mid_wait()
+                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist, ATROUS_TAIL))
+                if not hist_in_head and hooks is not None and hasattr(hooks, "hist_ready"):
+                    hooks.hist_ready(self._ev_hist)
         else:
+            if frame_mid_exchange(self.params)[0] >= 0:
+                raise ValueError("exchange_iteration >= 0 needs the serial (single-stream) frame: pipelined=False")
             sa, sb = self.stream_a, self.stream_b
             # The side streams keep reading color / nd / motion and writing `out` after this call returns (nd
             # until the NEXT frame's T has run): tell torch's caching allocator, so that a caller who drops or

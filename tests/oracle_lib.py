@@ -129,7 +129,7 @@ def default_params():
     """SURVEY Appendix A defaults (kept independent of librmd's rmd_svgf_default_params; a test compares them)."""
     return SvgfParams(alpha_color=0.05, alpha_moments=0.2, h_max=32, k_z=10.0, k_n=0.9, max_motion_rows=64,
                       var_h_threshold=4, var_radius=3, sigma_n=128.0, sigma_z=1.0, sigma_l=4.0,
-                      iterations=5, hist_iteration=0, atrous_variant=0, tv_workgroups=0, atrous_cus=0)
+                      iterations=5, hist_iteration=0, atrous_variant=0, tv_workgroups=0, atrous_cus=0, exchange_iteration=-1)
 
 
 # ---- box filter ------------------------------------------------------------------------------

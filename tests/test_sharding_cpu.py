@@ -52,6 +52,38 @@ def test_sends_and_receives_pair_up():
     assert sharding.halo_bytes(plans[1], 3840) == 2 * (13 + 8) * 3840 * 16
 
 
+REACH_X3 = (34, 41, 28, 33)       # the same with exchange_iteration = 3: T / V / A0..A2 on 32 fewer rows per side
+MID_X3 = (3, 32)                  # frame_mid_exchange: iteration 3's output, 32 rows per side
+
+
+def test_mid_frame_exchange_plan_pairs_up():
+    """exchange_iteration = 3: every rank receives the 32 rows beyond either end of its strip from the neighbour that
+    OWNS them (it computed iteration 3 on its own rows only), in matching order; buffers cover the received rows."""
+    world, height = 8, 4320
+    plans = [sharding.make_plan(height, world, r, REACH_X3, MID_X3) for r in range(world)]
+    steps = [sharding.mid_halo_plan(p) for p in plans]
+    for r in range(world):
+        p = plans[r]
+        assert p.buf_row0 == max(0, p.row0 - 41) and p.buf_row0 + p.buf_rows == min(height, p.row1 + 41)
+        for peer in (r - 1, r + 1):
+            if not 0 <= peer < world:
+                continue
+            recvs = [(lo, hi) for k, n, lo, hi, q in steps[r] if k == "recv" and q == peer]
+            sends = [(lo, hi) for k, n, lo, hi, q in steps[peer] if k == "send" and q == r]
+            assert recvs == sends and len(recvs) == 1 and recvs[0][1] - recvs[0][0] == 32
+            lo, hi = recvs[0]
+            assert plans[peer].row0 <= lo and hi <= plans[peer].row1          # sent rows are the sender's own rows
+            assert hi == p.row0 or lo == p.row1                               # and touch this rank's strip
+            assert p.buf_row0 <= lo and hi <= p.buf_row0 + p.buf_rows
+    assert sharding.mid_halo_plan(sharding.make_plan(height, 1, 0, REACH_X3, MID_X3)) == []
+    assert sharding.mid_halo_plan(sharding.make_plan(height, 8, 3, REACH)) == []          # no exchange_iteration: nothing travels
+    assert sharding.mid_halo_bytes(plans[1], 7680) == 2 * 32 * 7680 * 16
+    assert sharding.mid_halo_bytes(plans[0], 7680) == 32 * 7680 * 16
+    assert sharding.halo_bytes(plans[1], 7680) == 2 * (13 + 8) * 7680 * 16               # history halo: rows (28, 41] and (33, 41]
+    with pytest.raises(ValueError):
+        sharding.make_plan(240, 8, 0, (34, 20, 28, 33), MID_X3)                            # 30-row strips < 32 exchanged rows
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -86,6 +118,14 @@ def _worker(rank, world, port, height, width, result):
         lo, hi = max(0, plan.row0 - plan.reach_hist), min(height, plan.row1 + plan.reach_hist)
         for pid, t in enumerate(planes):
             ok = ok and torch.equal(t[lo - plan.buf_row0:hi - plan.buf_row0], _truth((lo, hi), width, pid))
+        # the mid-frame exchange: a plane that holds only the rank's OWN rows gets the 32 rows on either side
+        plan = sharding.make_plan(height, world, rank, REACH_X3, MID_X3)
+        t = torch.full((plan.buf_rows, width, 4), -1.0)
+        t[plan.row0 - plan.buf_row0:plan.row1 - plan.buf_row0] = _truth((plan.row0, plan.row1), width, 2)
+        n = sharding.exchange_mid_halo(plan, t)
+        ok = ok and n == len(sharding.mid_halo_plan(plan))
+        lo, hi = max(0, plan.row0 - 32), min(height, plan.row1 + 32)
+        ok = ok and torch.equal(t[lo - plan.buf_row0:hi - plan.buf_row0], _truth((lo, hi), width, 2))
         result[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

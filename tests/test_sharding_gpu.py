@@ -21,7 +21,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, width, height, frames, result):
+def _worker(rank, world, port, width, height, frames, exchange_iteration, result):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -31,8 +31,9 @@ def _worker(rank, world, port, width, height, frames, result):
         torch.cuda.set_device(0)
         p = rmd.default_params()
         p.max_motion_rows = 8
+        single = rmd.SvgfDenoiser(width, height, params=rmd.SvgfParams.from_buffer_copy(p))
+        p.exchange_iteration = exchange_iteration          # the strips: redundant rows only, or one exchange inside the frame
         sd = sharding.ShardedDenoiser(width, height, params=p, rank=rank, world=world)
-        single = rmd.SvgfDenoiser(width, height, params=p)
         ok = True
         for f in range(frames):
             c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
@@ -47,12 +48,13 @@ def _worker(rank, world, port, width, height, frames, result):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange_iteration", [-1, 3])
 @pytest.mark.parametrize("world", [2, 3])
-def test_strips_over_torch_distributed_match_single_device(cuda, world):
+def test_strips_over_torch_distributed_match_single_device(cuda, world, exchange_iteration):
     ctx = mp.get_context("spawn")
     result = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, 160, 420, 4, result)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, 160, 420, 4, exchange_iteration, result)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

@@ -17,26 +17,31 @@ def c_plan(rmd, height, world, rank, p):
     return plan
 
 
-def c_steps(rmd, plan):
+def c_steps(rmd, plan, fn=None):
     steps = (HaloStep * 8)()
     n = C.c_int()
-    rmd.check(lib.rmd_halo_plan(C.byref(plan), steps, 8, C.byref(n)))
+    rmd.check((fn or lib.rmd_halo_plan)(C.byref(plan), steps, 8, C.byref(n)))
     kind = {HaloStep.RECV: "recv", HaloStep.SEND: "send"}
-    name = {0: "color", 1: "moments"}
+    name = {0: "color", 1: "moments", 2: "mid"}
     return [(kind[s.kind], name[s.plane], s.row_lo, s.row_hi, s.peer) for s in steps[:n.value]]
 
 
+@pytest.mark.parametrize("exchange_iteration", [-1, 3, 2, 0])
 @pytest.mark.parametrize("height,world", [(4320, 8), (4320, 4), (4320, 2), (2160, 4), (1000, 3), (420, 2), (300, 1), (4321, 8)])
-def test_c_planner_equals_python_planner(rmd, height, world):
+def test_c_planner_equals_python_planner(rmd, height, world, exchange_iteration):
     p = rmd.default_params()
     p.max_motion_rows = 8
-    reach = rmd.svgf.frame_reach(p)
+    p.exchange_iteration = exchange_iteration
+    reach, mid = rmd.svgf.frame_reach(p), rmd.svgf.frame_mid_exchange(p)
+    assert mid == ((exchange_iteration, {3: 32, 2: 48, 0: 60}[exchange_iteration]) if exchange_iteration >= 0 else (-1, 0))
     for rank in range(world):
-        want = sharding.make_plan(height, world, rank, reach)
+        want = sharding.make_plan(height, world, rank, reach, mid)
         got = c_plan(rmd, height, world, rank, p)
-        for f in ("height", "world", "rank", "row0", "row1", "buf_row0", "buf_rows", "reach_in", "reach_hist", "have_color", "have_moments"):
+        for f in ("height", "world", "rank", "row0", "row1", "buf_row0", "buf_rows", "reach_in", "reach_hist", "have_color", "have_moments",
+                  "mid_iteration", "mid_rows"):
             assert getattr(got, f) == getattr(want, f), (rank, f)
         assert c_steps(rmd, got) == sharding.halo_plan(want), rank
+        assert c_steps(rmd, got, lib.rmd_mid_halo_plan) == sharding.mid_halo_plan(want), rank
         assert lib.rmd_halo_bytes(C.byref(got), 7680) == sharding.halo_bytes(want, 7680)
         r0, r1 = C.c_int(), C.c_int()
         rmd.check(lib.rmd_strip_rows(height, world, rank, C.byref(r0), C.byref(r1)))
@@ -52,6 +57,22 @@ def test_other_parameters_change_the_plan_the_same_way(rmd):
         got = c_plan(rmd, 2160, 4, rank, p)
         assert c_steps(rmd, got) == sharding.halo_plan(want)
         assert (got.buf_row0, got.buf_rows) == (want.buf_row0, want.buf_rows)
+
+
+def test_reach_with_one_exchange_inside_the_frame(rmd):
+    """exchange_iteration = 3 (SURVEY §8e "Halo sizes"): A3 on the strip's own rows, its 32-row halo travels; T / V / A0..A2
+    run on 32 fewer rows per side than with redundant rows only."""
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    assert rmd.svgf.frame_reach(p) == (66, 73, 60, 65)
+    p.exchange_iteration = 3
+    assert rmd.svgf.frame_reach(p) == (34, 41, 28, 33) and rmd.svgf.frame_mid_exchange(p) == (3, 32)
+    p.exchange_iteration = 4                                                             # the last iteration: nothing to exchange for
+    with pytest.raises(rmd.RmdError):
+        rmd.svgf.frame_reach(p)
+    p.exchange_iteration = 0
+    p.hist_iteration = 0                                                                 # the history iteration IS the exchanged one:
+    assert rmd.svgf.frame_reach(p)[2] == 60                                              # its own rows + the 60 received
 
 
 def test_short_strips_and_bad_arguments_are_rejected(rmd):

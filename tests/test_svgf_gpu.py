@@ -389,20 +389,51 @@ def test_c_context_matches_python_denoiser(rmd, cuda):
 
 
 def simulate_strips(rmd, width, height, world, frames, p):
-    """All ranks of a row-strip deployment in one process: each 'rank' owns a ShardedDenoiser,
-    the halo exchange is done by copying exactly the rows sharding.halo_plan() names."""
+    """All ranks of a row-strip deployment in one process: each 'rank' owns a ShardedDenoiser, the exchanges are done by
+    copying exactly the rows sharding.halo_plan() / mid_halo_plan() name.  With p.exchange_iteration = X >= 0 the frame runs in
+    the parts of rmd_svgf_frame_atrous_part: every rank's T + V + A0..AX, then the mid-frame exchange of AX's halo rows (poisoned
+    with NaN beforehand: they must come from the neighbour), then the rest."""
+    import ctypes as C
     from raymarchdenoisercuda_amd import sharding
+    lib = rmd.lib
     ranks = [sharding.ShardedDenoiser(width, height, params=p, rank=r, world=world) for r in range(world)]
-    for r in ranks:
-        r.world_for_exchange = world
+    mid = rmd.svgf.frame_mid_exchange(p)[0]
     outs = []
     for f in range(frames):
         full = torch.zeros((height, width, 4), device="cuda")
+        work = []
         for r in ranks:
             c, nd, m = r.synth(f)
-            o = r.den.denoise(c, nd, m, None, r.plan.row0, r.plan.row1)
+            a, b = r.plan.row0 - r.plan.buf_row0, r.plan.row1 - r.plan.buf_row0
+            if mid < 0:
+                o = r.den.denoise(c, nd, m, None, r.plan.row0, r.plan.row1)
+                full[r.plan.row0:r.plan.row1] = o[a:b]
+                continue
+            o = torch.empty_like(c)
+            d = r.den.describe(c, nd, m, o)
+            plane = r.den.iteration_plane(mid, o)
+            plane[:a] = float("nan")
+            plane[b:] = float("nan")
+            rmd.check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(p), r.plan.row0, r.plan.row1, None))
+            rmd.check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), r.plan.row0, r.plan.row1, None, None, rmd.svgf.ATROUS_HEAD))
+            work.append((r, d, plane, o, (c, nd, m)))
+        planes = {r.rank: plane for r, _, plane, _, _ in work}
+        for r, d, plane, o, _ in work:                    # the mid-frame exchange, by plan
+            steps = sharding.mid_halo_plan(r.plan)
+            assert len(steps) == (4 if 0 < r.rank < world - 1 else 2)
+            for kind, name, lo, hi, peer in steps:
+                if kind != "recv":
+                    continue
+                q = ranks[peer]
+                assert q.plan.row0 <= lo and hi <= q.plan.row1, "a halo row must come from its owner"
+                plane[lo - r.plan.buf_row0:hi - r.plan.buf_row0] = planes[peer][lo - q.plan.buf_row0:hi - q.plan.buf_row0]
+        for r, d, plane, o, (c, nd, m) in work:
+            for part in (rmd.svgf.ATROUS_INTERIOR, rmd.svgf.ATROUS_TAIL):
+                rmd.check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), r.plan.row0, r.plan.row1, None, None, part))
+            r.den.cur ^= 1
+            r.den.has_history, r.den.prev_nd = True, nd
             full[r.plan.row0:r.plan.row1] = o[r.plan.row0 - r.plan.buf_row0:r.plan.row1 - r.plan.buf_row0]
-        for r in ranks:                                   # the exchange, by plan
+        for r in ranks:                                   # the history exchange, by plan
             hist = dict(zip(("color", "moments"), r.den.history()))
             for kind, name, lo, hi, peer in sharding.halo_plan(r.plan):
                 if kind != "recv":
@@ -415,10 +446,12 @@ def simulate_strips(rmd, width, height, world, frames, p):
     return outs
 
 
+@pytest.mark.parametrize("exchange_iteration", [-1, 3, 2, 0])
 @pytest.mark.parametrize("world,height", [(2, 420), (3, 420), (8, 1200)])
-def test_row_strips_are_bit_identical_to_one_gpu(rmd, cuda, world, height):
+def test_row_strips_are_bit_identical_to_one_gpu(rmd, cuda, world, height, exchange_iteration):
     """SURVEY §8e 'Parity across G': strip outputs are the bits of the single-device result
-    (8 strips = the driver's largest run: interior ranks exchange with both neighbours)."""
+    (8 strips = the driver's largest run: interior ranks exchange with both neighbours), with redundant rows only
+    (exchange_iteration -1) and with one neighbour exchange inside the frame."""
     width, frames = 160, 4
     p = rmd.default_params()
     p.max_motion_rows = 8
@@ -427,13 +460,15 @@ def test_row_strips_are_bit_identical_to_one_gpu(rmd, cuda, world, height):
     for f in range(frames):
         c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
         want.append(single.denoise(c, nd, m).clone())
+    p.exchange_iteration = exchange_iteration
     got = simulate_strips(rmd, width, height, world, frames, p)
     torch.cuda.synchronize()
     for f in range(frames):
         assert torch.equal(got[f], want[f]), f"world {world} frame {f}: {(got[f] != want[f]).sum().item()} values differ"
 
 
-def test_8k_frame_in_8_row_strips_is_bit_identical_to_one_gpu(rmd, cuda):
+@pytest.mark.parametrize("exchange_iteration", [-1, 3])
+def test_8k_frame_in_8_row_strips_is_bit_identical_to_one_gpu(rmd, cuda, exchange_iteration):
     """BASELINE configs[3] at its own size: the 7680x4320 frame cut into 8 strips of 540 rows (what
     `bench.py --gpus 8` runs, one strip per rank) gives the bits of the unsharded 8K frame, over
     3 frames so the exchanged history halo rows are read back by the temporal pass."""
@@ -446,6 +481,7 @@ def test_8k_frame_in_8_row_strips_is_bit_identical_to_one_gpu(rmd, cuda):
         c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
         want.append(single.denoise(c, nd, m).clone())
     del single
+    p.exchange_iteration = exchange_iteration
     got = simulate_strips(rmd, width, height, world, frames, p)
     torch.cuda.synchronize()
     for f in range(frames):
