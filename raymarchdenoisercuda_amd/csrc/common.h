@@ -76,6 +76,9 @@ int launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int 
                     bool sparse_t_color);
 int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused,
                     bool sparse_t_color);
+// T + V of a whole frame in one launch (no statistics, var_radius 3): a workgroup that finds short-history pixels in its tile
+// recomputes T on the tile's 3-pixel halo and runs V for them itself (svgf_temporal.hip)
+int launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, int v_row0, int v_row1, void* stream);
 bool variance_reads_sparse_t_color(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, bool fused);
 
 }  // namespace rmd

@@ -146,11 +146,14 @@ int rmd_svgf_frame_tv(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, in
     // T also fills v_color, so V only rewrites short-history pixels (when statistics are wanted V
     // runs unfused: it then has to visit every pixel anyway)
     const bool fuse = f->stats == nullptr;
+    const int t0 = clampi(row0 - r.t, 0, H), t1 = clampi(row1 + r.t, 0, H);
+    const int v0 = clampi(row0 - r.v, 0, H), v1 = clampi(row1 + r.v, 0, H);
+    // no statistics, the default window, one workgroup per tile: T and V in ONE launch (svgf_temporal_variance_kernel)
+    if (fuse && p->var_radius == 3 && p->tv_workgroups == 0 && p->var_h_threshold <= 256 && tuning_env("RMD_FUSED_TV", 1))
+        return launch_temporal_variance(f, p, t0, t1, v0, v1, stream);
     // one decision for both passes: T skips the t_color stores V will not read
     const bool sparse = variance_reads_sparse_t_color(f, p, fuse);
-    const int t0 = clampi(row0 - r.t, 0, H), t1 = clampi(row1 + r.t, 0, H);
     if (int e = launch_temporal(f, p, t0, t1, stream, fuse, sparse)) return e;
-    const int v0 = clampi(row0 - r.v, 0, H), v1 = clampi(row1 + r.v, 0, H);
     return launch_variance(f, p, v0, v1, stream, fuse, sparse);
 }
 

@@ -11,25 +11,9 @@
 // they match oracle/svgf_oracle.c:orc_svgf_temporal bit for bit; so do the float outputs
 // (IEEE division, no transcendental functions in this pass).
 #include "common.h"
+#include "svgf_tv.h"
 
 namespace rmd {
-
-struct TemporalArgs {
-    Geom g;
-    const float4* color; const float4* nd; const float2* motion;
-    const float4* hist_color; const float4* hist_moments; const float4* prev_nd;
-    float4* t_color; float4* t_moments; int4* t_debug;
-    float4* v_color;          // optional second copy of t_color (fused frame: V then only rewrites short-history pixels)
-    unsigned char* tile_flags; // optional: 1 per 64x4 tile (global tiling) holding a pixel with h < var_h_threshold
-    int tiles_x, var_h_threshold;
-    int sparse_t_color;        // fused frame with the tile form of V: t_color is written only inside flagged tiles (V reads
-                               // every other pixel of its windows from v_color, which holds the same values there)
-    int row0, row1;
-    float alpha_color, alpha_moments, k_z, k_n;
-    int h_max, max_motion_rows;
-};
-
-__device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 
 // One 64x4 tile of the GLOBAL tiling (rows 4k..4k+3, so T and V agree on tiles) by one workgroup.
 __device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int tile_x, const int tile_y)
@@ -42,105 +26,110 @@ __device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int t
     float4 tc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     size_t i = 0;
     if (active) {
-    i = pix_index(g, x, y);
-
-    const float4 c = a.color[i];
-    const float4 nd = a.nd[i];
-    const float2 m = a.motion[i];
-
-    // A.T.1
-    const float qx = (float)x + m.x, qy = (float)y + m.y;
-    const float fqx = floorf(qx), fqy = floorf(qy);
-    const int q0x = (int)fqx, q0y = (int)fqy;
-    const float fx = qx - fqx, fy = qy - fqy;
-    const float wk[4] = { (1.0f - fx) * (1.0f - fy), fx * (1.0f - fy), (1.0f - fx) * fy, fx * fy };
-
-    // A.T.2: depth gradient by forward differences clamped at the border
-    const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
-    const float zr = a.nd[pix_index(g, x1, y)].w;
-    const float zd = a.nd[pix_index(g, x, y1)].w;
-    const float gz = fabsf(zr - nd.w) + fabsf(zd - nd.w);
-    const float zthr = a.k_z * (gz + 1e-2f);
-    const bool p_zero = is_zero3(nd);
-
-    int mask = 0;
-    float wsum = 0.0f, pcx = 0.0f, pcy = 0.0f, pcz = 0.0f, pm1 = 0.0f, pm2 = 0.0f;
-    float best_w = -1.0f;
-    int best_h = 0;
-    if (a.prev_nd) {                               // NULL = no history yet (first frame / after a reset)
-        // All twelve history gathers are issued up front, at tap coordinates clamped into the rows
-        // the planes hold, and validity is decided afterwards: a dependent load-test-load chain per
-        // tap keeps too few bytes in flight for an HBM-bound pass.  Same arithmetic, same order.
-        const int ylo = max(max(g.buf_row0, 0), y - a.max_motion_rows);
-        const int yhi = min(min(g.buf_row0 + g.buf_rows, g.H) - 1, y + a.max_motion_rows);
-        size_t ti[4];
-        bool inb[4];
-        float4 pn[4], hc[4], hm[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int tx = q0x + (k & 1), ty = q0y + (k >> 1);
-            inb[k] = tx >= 0 && tx < g.W && ty >= 0 && ty < g.H && abs(ty - y) <= a.max_motion_rows;
-            ti[k] = pix_index(g, min(max(tx, 0), g.W - 1), min(max(ty, ylo), yhi));
-        }
-        // Two batches: the four prev_nd gathers decide tap validity; only then the eight
-        // hist_color / hist_moments gathers are issued.  The fence keeps the register footprint at
-        // <= 56 VGPRs, so that one wave of this kernel fits on a SIMD beside three a-trous waves
-        // (3 x 152 of 512 registers) when frames are pipelined over two streams.
-#pragma unroll
-        for (int k = 0; k < 4; ++k) pn[k] = a.prev_nd[ti[k]];
-        bool ok[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const bool ok_n = p_zero ? is_zero3(pn[k]) : ((pn[k].x * nd.x + pn[k].y * nd.y + pn[k].z * nd.z) >= a.k_n);
-            ok[k] = inb[k] && (fabsf(pn[k].w - nd.w) <= zthr) && ok_n;
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { hc[k] = a.hist_color[ti[k]]; hm[k] = a.hist_moments[ti[k]]; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!ok[k]) continue;
-            mask |= 1 << k;
-            const float w = wk[k];
-            wsum += w;
-            pcx += w * hc[k].x; pcy += w * hc[k].y; pcz += w * hc[k].z;
-            pm1 += w * hm[k].x; pm2 += w * hm[k].y;
-            if (w > best_w) { best_w = w; best_h = (int)hm[k].z; }
-        }
-    }
-
-    // A.T.3
-    int h;
-    if (mask != 0 && wsum >= 0.01f) {
-        pcx /= wsum; pcy /= wsum; pcz /= wsum; pm1 /= wsum; pm2 /= wsum;
-        h = min(best_h + 1, a.h_max);
-        h = max(h, 1);
-    } else {
-        h = 1;
-        pcx = pcy = pcz = 0.0f; pm1 = pm2 = 0.0f;
-    }
-
-    // A.T.4
-    const float inv_h = 1.0f / (float)h;
-    const float a_c = a.alpha_color > inv_h ? a.alpha_color : inv_h;
-    const float a_m = a.alpha_moments > inv_h ? a.alpha_moments : inv_h;
-    const float l = lum3(c.x, c.y, c.z);
-    const float m1 = lerpf(pm1, l, a_m), m2 = lerpf(pm2, l * l, a_m);
-    float var = m2 - m1 * m1;
-    if (!(var > 0.0f)) var = 0.0f;
-
-    tc = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
-    if (!a.sparse_t_color) a.t_color[i] = tc;
-    if (a.v_color) a.v_color[i] = tc;
-    a.t_moments[i] = make_float4(m1, m2, (float)h, 0.0f);
-    if (a.t_debug) a.t_debug[i] = make_int4(q0x, q0y, mask, h);
-    short_history = h < a.var_h_threshold;
+        i = pix_index(g, x, y);
+        float4 mom;
+        int4 dbg;
+        temporal_pixel(a, x, y, tc, mom, dbg);
+        if (!a.sparse_t_color) a.t_color[i] = tc;
+        if (a.v_color) a.v_color[i] = tc;
+        a.t_moments[i] = mom;
+        if (a.t_debug) a.t_debug[i] = dbg;
+        short_history = dbg.w < a.var_h_threshold;
     }
     if (a.tile_flags) {
         const int any = __syncthreads_or(short_history ? 1 : 0);
         if (threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + tile_x] = (unsigned char)(any != 0);
         // 16 of T's 136 B per pixel: in the steady state ~2 % of the tiles are flagged
         if (a.sparse_t_color && any && active) a.t_color[i] = tc;
+    }
+}
+
+// Whole frames (rmd_svgf_frame_tv): T and V in ONE launch.  V rewrites only the pixels with a short history (~10 k of 8.3 M
+// at 4K in the steady state, in ~2 % of the tiles), but as a launch of its own it cost 26-30 us at EVERY frame size -- an empty
+// grid, a flag scan, a dependent chain of loads per flagged tile (10 % of a 1080p frame).  Here the workgroup that finds a
+// short-history pixel in its tile finishes the job itself: V needs T's output on the tile + 3 pixels around it, which other
+// workgroups own and may not have written yet, so it RECOMPUTES T for those 444 halo pixels (same code, same bits; 2 % of the
+// tiles x 2.7 = +4 % of T's arithmetic), stages tile + halo in LDS and runs the 49 taps for its short-history pixels, compacted
+// to the first lanes.  No t_color plane, no second launch; v_color gets T's value or V's, t_moments and the tile flags as before.
+struct FusedVArgs {
+    int row0, row1;           // rows V is responsible for (a strip: fewer than T's, whose output V's windows tap)
+    int h_threshold;
+    float sigma_n, sigma_z;
+};
+
+__global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArgs a, FusedVArgs v)
+{
+    __shared__ float4 sc[kVH][kVW], sn[kVH][kVW];
+    __shared__ unsigned short todo[256];
+    __shared__ unsigned long long wave_mask[4];
+    const Geom g = a.g;
+    // Tile rows are dealt out edges first (bottom row, top row, then the rest): the tiles with short-history pixels sit along
+    // the frame edges the camera moves away from, and their workgroups live 3-4 x longer than the others -- at the end of
+    // the grid they would be the launch's tail.
+    const int rows_y = (int)gridDim.y;
+    const int by = blockIdx.y == 0 ? rows_y - 1 : (int)blockIdx.y - 1;
+    const int tile_x = blockIdx.x, tile_y = a.row0 / 4 + by;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const int x0 = tile_x * 64, y0 = tile_y * 4;
+    const int x = x0 + lx, y = y0 + ly;
+    const bool active = x < g.W && y >= a.row0 && y < a.row1;
+    float4 tc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    int h = 0;
+    bool spatial = false;
+    if (active) {
+        const size_t i = pix_index(g, x, y);
+        float4 mom;
+        int4 dbg;
+        temporal_pixel(a, x, y, tc, mom, dbg);
+        a.t_moments[i] = mom;
+        if (a.t_debug) a.t_debug[i] = dbg;
+        h = dbg.w;
+        spatial = h < v.h_threshold && y >= v.row0 && y < v.row1;
+        if (!spatial) a.v_color[i] = tc;          // (a short-history pixel gets its value below, from another lane)
+    }
+    const unsigned long long mine = __builtin_amdgcn_ballot_w64(spatial);     // bit = column, wave = row of the tile
+    if (lx == 0) wave_mask[ly] = mine;
+    const int any = __syncthreads_or(spatial ? 1 : 0);
+    if (a.tile_flags && threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + tile_x] = (unsigned char)(any != 0);
+    if (!any) return;
+
+    // ---- T's output and nd on the tile + halo into LDS -- only where a 7x7 window of a short-history pixel can reach: the
+    // bounding box of those pixels + 3 (a band along a frame edge needs ~70 halo pixels, not 444).  Own pixel from
+    // registers, halo pixels recomputed.
+    const unsigned long long m0 = wave_mask[0], m1 = wave_mask[1], m2 = wave_mask[2], m3 = wave_mask[3];
+    const unsigned long long cols = m0 | m1 | m2 | m3;
+    const int bx0 = __builtin_ctzll(cols) - kVR, bx1 = 63 - __builtin_clzll(cols) + kVR;            // tile coordinates, inclusive
+    const int by0 = (m0 ? 0 : m1 ? 1 : m2 ? 2 : 3) - kVR, by1 = (m3 ? 3 : m2 ? 2 : m1 ? 1 : 0) + kVR;
+    if (active) {
+        sc[ly + kVR][lx + kVR] = tc;
+        sn[ly + kVR][lx + kVR] = a.nd[pix_index(g, x, y)];
+    }
+    for (int q = threadIdx.x; q < kVW * kVH; q += 256) {
+        const int ry = q / kVW, rx = q - ry * kVW;
+        if (ry >= kVR && ry < kVR + 4 && rx >= kVR && rx < kVR + 64) continue;            // the tile itself
+        if (rx - kVR < bx0 || rx - kVR > bx1 || ry - kVR < by0 || ry - kVR > by1) continue; // no window reaches it
+        const int tx = x0 - kVR + rx, ty = y0 - kVR + ry;
+        // pixels outside the frame are never tapped (A.V skips them); neither are rows outside T's range: V's rows lie
+        // at least 3 rows inside it wherever the frame goes on (launch_temporal_variance)
+        if (tx < 0 || tx >= g.W || ty < a.row0 || ty >= a.row1) continue;
+        float4 hc, mom;
+        int4 dbg;
+        temporal_pixel(a, tx, ty, hc, mom, dbg);
+        sc[ry][rx] = hc;
+        sn[ry][rx] = a.nd[pix_index(g, tx, ty)];
+    }
+    // ---- the short-history pixels of the tile, compacted to the first lanes (a wave with one such lane pays for the whole
+    // 49-tap body), as svgf_variance_tile_kernel does
+    const int c0 = __builtin_popcountll(m0), c1 = __builtin_popcountll(m1), c2 = __builtin_popcountll(m2), c3 = __builtin_popcountll(m3);
+    if (spatial) {
+        const int before = ly == 0 ? 0 : ly == 1 ? c0 : ly == 2 ? c0 + c1 : c0 + c1 + c2;
+        todo[before + __builtin_popcountll(mine & ((1ull << lx) - 1ull))] = (unsigned short)(threadIdx.x | (h << 8));
+    }
+    __syncthreads();                                       // todo[] and the staged region are complete
+    if ((int)threadIdx.x < c0 + c1 + c2 + c3) {
+        const int id = todo[threadIdx.x];
+        const int px = id & 63, py = (id >> 6) & 3;
+        a.v_color[pix_index(g, x0 + px, y0 + py)] = variance_window_lds(sc, sn, px, py, x0 + px, y0 + py, g, v.sigma_n, v.sigma_z, id >> 8);
     }
 }
 
@@ -227,6 +216,50 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
         hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
     }
     RMD_LAUNCH_CHECK("svgf_temporal_kernel");
+    return RMD_OK;
+}
+
+// T + V of a whole frame in one launch (svgf_temporal_variance_kernel): T on rows [row0,row1), V on [v_row0,v_row1).
+int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, int v_row0, int v_row1, void* stream)
+{
+    if (int e = check_frame_geometry(f)) return e;
+    if (!p) return fail(RMD_E_NULL, "rmd_svgf_frame_tv: params is NULL");
+    if (!f->color || !f->nd || !f->motion || !f->t_moments || !f->v_color)
+        return fail(RMD_E_NULL, "rmd_svgf_frame_tv: a required plane is NULL");
+    const bool has_hist = f->hist_color && f->hist_moments && f->prev_nd;
+    if (!has_hist && (f->hist_color || f->hist_moments || f->prev_nd))
+        return fail(RMD_E_NULL, "rmd_svgf_frame_tv: history planes must be all set or all NULL");
+    if (row0 < 0 || row1 > f->height || row0 >= row1 || v_row0 < row0 || v_row1 > row1 || v_row0 >= v_row1)
+        return fail(RMD_E_ROWS, "rmd_svgf_frame_tv: rows T [%d,%d) V [%d,%d) invalid", row0, row1, v_row0, v_row1);
+    // V's windows must find T's output (recomputed in the kernel) inside T's rows wherever the frame goes on
+    if ((v_row0 - kVR < row0 && row0 > 0) || (v_row1 + kVR > row1 && row1 < f->height))
+        return fail(RMD_E_ROWS, "rmd_svgf_frame_tv: V rows [%d,%d) need T on %d more rows than [%d,%d)", v_row0, v_row1, kVR, row0, row1);
+    if (p->var_radius != kVR) return fail(RMD_E_PARAM, "rmd_svgf_frame_tv: the fused kernel is built for var_radius %d", kVR);
+    if (p->max_motion_rows < 0 || p->h_max < 1) return fail(RMD_E_PARAM, "rmd_svgf_frame_tv: max_motion_rows/h_max invalid");
+    if (int e = check_rows_in_buffer(f, row0, row1 + 1, "rmd_svgf_frame_tv (current frame)")) return e;
+    if (has_hist)
+        if (int e = check_rows_in_buffer(f, row0 - p->max_motion_rows, row1 + p->max_motion_rows, "rmd_svgf_frame_tv (history)")) return e;
+    const void* planes16[] = { f->color, f->nd, f->hist_color, f->hist_moments, f->prev_nd, f->v_color, f->t_moments, f->t_debug };
+    for (const void* q : planes16)
+        if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_frame_tv: float4 planes must be 16-byte aligned");
+    if (!aligned_to(f->motion, 8)) return fail(RMD_E_ALIGN, "rmd_svgf_frame_tv: motion must be 8-byte aligned");
+
+    TemporalArgs a;
+    a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
+    a.color = (const float4*)f->color; a.nd = (const float4*)f->nd; a.motion = (const float2*)f->motion;
+    a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float4*)f->hist_moments;
+    a.prev_nd = (const float4*)f->prev_nd;
+    a.t_color = nullptr; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
+    a.v_color = (float4*)f->v_color;
+    a.sparse_t_color = 0;
+    a.tile_flags = f->v_tile_flags; a.tiles_x = (f->width + 63) / 64; a.var_h_threshold = p->var_h_threshold;
+    a.row0 = row0; a.row1 = row1;
+    a.alpha_color = p->alpha_color; a.alpha_moments = p->alpha_moments; a.k_z = p->k_z; a.k_n = p->k_n;
+    a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
+    FusedVArgs v = { v_row0, v_row1, p->var_h_threshold, p->sigma_n, p->sigma_z };
+    dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
+    hipLaunchKernelGGL(svgf_temporal_variance_kernel, grid, dim3(256), 0, as_stream(stream), a, v);
+    RMD_LAUNCH_CHECK("svgf_temporal_variance_kernel");
     return RMD_OK;
 }
 

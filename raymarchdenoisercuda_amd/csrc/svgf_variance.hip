@@ -11,6 +11,7 @@
 // butterflies and committed with one atomic per wave.
 #include <cstdlib>
 #include "common.h"
+#include "svgf_tv.h"
 
 namespace rmd {
 
@@ -151,7 +152,6 @@ __global__ __launch_bounds__(256) void svgf_variance_kernel(VarianceArgs a)
 // identical bits.  4K steady state (~750 flagged tiles, ~10 k short-history pixels): 38 -> 26 us, of which 4.5 are
 // the empty launch, 2.4 the staging and the rest the tap bodies on the CUs that hold several flagged tiles;
 // a frame after a scene cut (every tile flagged): 670 -> 590 us.
-constexpr int kVR = 3, kVW = 64 + 2 * kVR, kVH = 4 + 2 * kVR;      // staged region 70 x 10
 constexpr int kVGrid = 2039;
 __global__ __launch_bounds__(256) void svgf_variance_tile_kernel(VarianceArgs a, int tiles_y)
 {
@@ -206,51 +206,7 @@ __global__ __launch_bounds__(256) void svgf_variance_tile_kernel(VarianceArgs a,
                 const int lx = id & 63, ly = (id >> 6) & 3;
                 h = id >> 8;
                 const int x = x0 + lx, y = y0 + ly;
-                const float4 c = sc[ly + kVR][lx + kVR];
-                const float4 nd = sn[ly + kVR][lx + kVR];
-                const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
-                const float gz = fabsf(sn[ly + kVR][x1 - x0 + kVR].w - nd.w) + fabsf(sn[y1 - y0 + kVR][lx + kVR].w - nd.w);
-                const float za = a.sigma_z * fmaxf(gz, 1e-8f);
-                const bool p_zero = is_zero3(nd);
-                float sw = 0.0f, scx = 0.0f, scy = 0.0f, scz = 0.0f, sl = 0.0f, sl2 = 0.0f;
-                // both loops unrolled: tap lengths become constants (nine distinct reciprocals instead of 48 square
-                // roots and divisions) and the LDS reads of neighbouring taps overlap -- the few lanes that get
-                // here are a latency chain, not a throughput problem
-#pragma unroll
-                for (int dx = -kVR; dx <= kVR; ++dx) {
-#pragma unroll
-                    for (int dy = -kVR; dy <= kVR; ++dy) {
-                        const int tx = x + dx, ty = y + dy;
-                        if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
-                        const float4 tc = sc[ly + kVR + dy][lx + kVR + dx];
-                        const float4 tn = sn[ly + kVR + dy][lx + kVR + dx];
-                        float e;
-                        const bool t_zero = is_zero3(tn);
-                        if (p_zero || t_zero) {
-                            e = (p_zero && t_zero) ? 0.0f : kNegInf;
-                        } else {
-                            const float d = __builtin_fmaf(nd.z, tn.z, __builtin_fmaf(nd.y, tn.y, nd.x * tn.x));
-                            e = a.sigma_n * fast_log2(fmaxf(d, 0.0f));
-                        }
-                        if (dx != 0 || dy != 0) {
-                            const float len = sqrtf((float)(dx * dx + dy * dy));
-                            e = __builtin_fmaf(-fabsf(nd.w - tn.w), kLog2e / (za * len + 1e-8f), e);
-                        }
-                        const float w = fast_exp2(e);
-                        const float tl = lum3(tc.x, tc.y, tc.z);
-                        sw += w;
-                        scx = __builtin_fmaf(w, tc.x, scx); scy = __builtin_fmaf(w, tc.y, scy); scz = __builtin_fmaf(w, tc.z, scz);
-                        sl = __builtin_fmaf(w, tl, sl); sl2 = __builtin_fmaf(w, tl * tl, sl2);
-                    }
-                }
-                float4 o = c;
-                if (!(sw < 1e-10f)) {
-                    const float el = sl / sw, el2 = sl2 / sw;
-                    float var = el2 - el * el;
-                    if (!(var > 0.0f)) var = 0.0f;
-                    var *= 4.0f / (float)max(h, 1);
-                    o = make_float4(scx / sw, scy / sw, scz / sw, var);
-                }
+                const float4 o = variance_window_lds(sc, sn, lx, ly, x, y, g, a.sigma_n, a.sigma_z, h);
                 a.v_color[pix_index(g, x, y)] = o;
             }
             __syncthreads();                                       // the next flagged tile restages the LDS region
