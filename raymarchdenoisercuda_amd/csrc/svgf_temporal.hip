@@ -55,6 +55,7 @@ struct FusedVArgs {
     int row0, row1;           // rows V is responsible for (a strip: fewer than T's, whose output V's windows tap)
     int h_threshold;
     float sigma_n, sigma_z;
+    int tiles_x, tiles_y;     // the launch's tile grid (one workgroup per tile, dealt out edges first)
 };
 
 __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArgs a, FusedVArgs v)
@@ -63,12 +64,20 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
     __shared__ unsigned short todo[256];
     __shared__ unsigned long long wave_mask[4];
     const Geom g = a.g;
-    // Tile rows are dealt out edges first (bottom row, top row, then the rest): the tiles with short-history pixels sit along
-    // the frame edges the camera moves away from, and their workgroups live 3-4 x longer than the others -- at the end of
-    // the grid they would be the launch's tail.
-    const int rows_y = (int)gridDim.y;
-    const int by = blockIdx.y == 0 ? rows_y - 1 : (int)blockIdx.y - 1;
-    const int tile_x = blockIdx.x, tile_y = a.row0 / 4 + by;
+    // Tiles are dealt out edges first (bottom row, top row, left column, right column, then the interior row by row): the
+    // tiles with short-history pixels sit along the frame edges the camera moves away from, and their workgroups live
+    // 3-4 x longer than the others -- at the end of the grid they would be the launch's tail.
+    int bx, by;
+    {
+        const int nx = v.tiles_x, ny = v.tiles_y, id = (int)blockIdx.x;
+        if (nx < 3 || ny < 3)               { bx = id % nx; by = id / nx; }
+        else if (id < nx)                   { bx = id; by = ny - 1; }
+        else if (id < 2 * nx)               { bx = id - nx; by = 0; }
+        else if (id < 2 * nx + (ny - 2))    { bx = 0; by = 1 + id - 2 * nx; }
+        else if (id < 2 * nx + 2 * (ny - 2)) { bx = nx - 1; by = 1 + id - 2 * nx - (ny - 2); }
+        else { const int k = id - 2 * nx - 2 * (ny - 2); bx = 1 + k % (nx - 2); by = 1 + k / (nx - 2); }
+    }
+    const int tile_x = bx, tile_y = a.row0 / 4 + by;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     const int x0 = tile_x * 64, y0 = tile_y * 4;
     const int x = x0 + lx, y = y0 + ly;
@@ -256,9 +265,9 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
     a.row0 = row0; a.row1 = row1;
     a.alpha_color = p->alpha_color; a.alpha_moments = p->alpha_moments; a.k_z = p->k_z; a.k_n = p->k_n;
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
-    FusedVArgs v = { v_row0, v_row1, p->var_h_threshold, p->sigma_n, p->sigma_z };
-    dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
-    hipLaunchKernelGGL(svgf_temporal_variance_kernel, grid, dim3(256), 0, as_stream(stream), a, v);
+    const int tiles_x = (f->width + 63) / 64, tiles_y = (row1 - 1) / 4 - row0 / 4 + 1;
+    FusedVArgs v = { v_row0, v_row1, p->var_h_threshold, p->sigma_n, p->sigma_z, tiles_x, tiles_y };
+    hipLaunchKernelGGL(svgf_temporal_variance_kernel, dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(256), 0, as_stream(stream), a, v);
     RMD_LAUNCH_CHECK("svgf_temporal_variance_kernel");
     return RMD_OK;
 }
