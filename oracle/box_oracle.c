@@ -103,6 +103,48 @@ void orc_weighted_filter(const uint8_t* render, uint8_t* denoised, uint8_t* buf0
         uint8_t* out = (level == p->depth - 1) ? denoised : buf[(level + 1) % 2];
         const int radius = mode == RMD_FILTER_WAVELET ? 2 : p->radius;
         const int step = mode == RMD_FILTER_WAVELET ? (1 << (p->level + level)) : 1;
+        if (mode == RMD_FILTER_GAUSSIAN) {
+            /* The Gaussian window is separable, w = g(dx) g(dy), g(d) = exp(-d^2 / (2 sigmaSpace^2)), and so is the
+             * renormalisation over the in-frame taps.  The ORDER OF EVALUATION is part of this build's definition (the
+             * result is truncated, so the last bit of the quotient decides bytes in flat regions): per row the
+             * horizontal sums H(x, y') = sum_dx g(dx) c(x+dx, y') for dx = -r..r inside the frame, then
+             * out = [sum_dy g(dy) H(x, y+dy)] / (hw(x) * vw(y)) with hw, vw the sums of the in-frame g(dx), g(dy);
+             * each accumulation one fused multiply-add (fmaf: a single rounding), the weight sums plain additions. */
+            float g[64];
+            for (int d = 0; d <= radius && d < 64; ++d) g[d] = expf(-(float)(d * d) * is_s);
+            float* hrow = (float*)malloc(sizeof(float) * (size_t)W * (size_t)H * 3);
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+                    for (int dx = -radius; dx <= radius; ++dx) {
+                        const int tx = x + dx;
+                        if (tx < 0 || tx >= W) continue;
+                        const uint8_t* c = in + ((size_t)y * W + tx) * 4;
+                        const float w = g[dx < 0 ? -dx : dx];
+                        sr = fmaf(w, (float)c[0], sr); sg = fmaf(w, (float)c[1], sg); sb = fmaf(w, (float)c[2], sb);
+                    }
+                    float* hp = hrow + ((size_t)y * W + x) * 3;
+                    hp[0] = sr; hp[1] = sg; hp[2] = sb;
+                }
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    float hw = 0.0f, vw = 0.0f, sr = 0.0f, sg = 0.0f, sb = 0.0f;
+                    for (int dx = -radius; dx <= radius; ++dx)
+                        if (x + dx >= 0 && x + dx < W) hw += g[dx < 0 ? -dx : dx];
+                    for (int dy = -radius; dy <= radius; ++dy) {
+                        const int ty = y + dy;
+                        if (ty < 0 || ty >= H) continue;
+                        const float* hp = hrow + ((size_t)ty * W + x) * 3;
+                        const float w = g[dy < 0 ? -dy : dy];
+                        sr = fmaf(w, hp[0], sr); sg = fmaf(w, hp[1], sg); sb = fmaf(w, hp[2], sb); vw += w;
+                    }
+                    const float sw = hw * vw;
+                    const size_t i = ((size_t)y * W + x) * 4;
+                    out[i] = (uint8_t)(sr / sw); out[i + 1] = (uint8_t)(sg / sw); out[i + 2] = (uint8_t)(sb / sw); out[i + 3] = 0;
+                }
+            free(hrow);
+            continue;
+        }
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 const size_t i = ((size_t)y * W + x) * 4;

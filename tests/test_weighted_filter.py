@@ -68,7 +68,10 @@ def gpu_run(rmd, img, p, normal=None, albedo=None):
     return out.cpu().numpy()
 
 
-def assert_close_u8(got, want):
+def assert_close_u8(got, want, exact=False):
+    if exact:                # GAUSSIAN: no transcendental on the device, the order of the fp32 operations is the oracle's
+        assert (got == want).all(), f"{(got != want).mean():.2e} of the bytes differ"
+        return
     diff = np.abs(got.astype(int) - want.astype(int))
     assert diff.max() <= 1, f"max byte difference {diff.max()}"
     assert (diff != 0).mean() < 2e-3, f"{(diff != 0).mean():.2e} of the bytes differ"
@@ -80,7 +83,7 @@ def test_cornell_against_oracle(rmd, orc, cuda, mode):
     render, normal, albedo = (orc.load_cornell(n) for n in ("render", "normal", "albedo"))
     for kw in (dict(depth=1), dict(depth=3, level=0), dict(depth=1, radius=4, sigmaSpace=2.5, level=2)):
         p = make_params(rmd, getattr(rmd.FilterParams, mode), **kw)
-        assert_close_u8(gpu_run(rmd, render, p, normal, albedo), orc.weighted_filter(render, p, normal, albedo))
+        assert_close_u8(gpu_run(rmd, render, p, normal, albedo), orc.weighted_filter(render, p, normal, albedo), exact=mode == "GAUSSIAN")
 
 
 @pytest.mark.gpu
@@ -91,9 +94,12 @@ def test_ragged_shapes_and_missing_planes(rmd, orc, cuda, shape):
     alb = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
     for mode in ("GAUSSIAN", "CROSS", "WAVELET"):
         p = make_params(rmd, getattr(rmd.FilterParams, mode), depth=2)
-        assert_close_u8(gpu_run(rmd, img, p, None, alb), orc.weighted_filter(img, p, None, alb))   # no normal plane
+        assert_close_u8(gpu_run(rmd, img, p, None, alb), orc.weighted_filter(img, p, None, alb), exact=mode == "GAUSSIAN")   # no normal plane
         p0 = make_params(rmd, getattr(rmd.FilterParams, mode), sigmaAlbedo=0.0, sigmaNormal=0.0)
-        assert_close_u8(gpu_run(rmd, img, p0), orc.weighted_filter(img, p0))
+        assert_close_u8(gpu_run(rmd, img, p0), orc.weighted_filter(img, p0), exact=mode == "GAUSSIAN")
+    for radius in (0, 1, 3, 7, 12):          # GAUSSIAN: every radius the separable kernel takes (1..4 unrolled, the rest at run time)
+        pg = make_params(rmd, rmd.FilterParams.GAUSSIAN, radius=radius, sigmaSpace=0.8 + radius)
+        assert_close_u8(gpu_run(rmd, img, pg), orc.weighted_filter(img, pg), exact=True)
 
 
 @pytest.mark.gpu
@@ -106,4 +112,7 @@ def test_parameter_errors(rmd, cuda):
     assert e.value.code == -3
     with pytest.raises(rmd.RmdError) as e:
         rmd.filterKernelTiled(g, make_params(rmd, rmd.FilterParams.WAVELET, level=12))
+    assert e.value.code == -3
+    with pytest.raises(rmd.RmdError) as e:
+        rmd.filterKernelTiled(g, make_params(rmd, rmd.FilterParams.GAUSSIAN, radius=13))
     assert e.value.code == -3
