@@ -651,7 +651,14 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             static_assert(kPieces <= NG || EDGE, "one refill instruction per tap group");
 #pragma unroll
             for (int grp = 0; grp < NG; ++grp) {
-                if (!EDGE && grp < kPieces) prefetch_piece(grp, j - 2 + C::NR, j + C::ADV);
+#ifndef RMD_PIECES_PER_GROUP
+#define RMD_PIECES_PER_GROUP 1
+#endif
+                if (!EDGE) {
+#pragma unroll
+                    for (int q = 0; q < RMD_PIECES_PER_GROUP; ++q)
+                        if (grp * RMD_PIECES_PER_GROUP + q < kPieces) prefetch_piece(grp * RMD_PIECES_PER_GROUP + q, j - 2 + C::NR, j + C::ADV);
+                }
                 if (grp & 1) { if (grp < NG - 1) load_grp(grp + 1, t0); weigh_grp(grp, t1); }
                 else         { if (grp < NG - 1) load_grp(grp + 1, t1); weigh_grp(grp, t0); }
                 __builtin_amdgcn_sched_barrier(0);

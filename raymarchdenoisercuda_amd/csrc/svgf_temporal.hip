@@ -60,7 +60,10 @@ struct FusedVArgs {
 
 __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArgs a, FusedVArgs v)
 {
-    __shared__ float4 sc[kVH][kVW], sn[kVH][kVW];
+    // 20 144 B of LDS: eight workgroups per CU, the occupancy of the plain T kernel (the pass is latency-bound: with two
+    // float4 planes, 23 KB, it ran at seven)
+    __shared__ float4 sn[kVH][kVW];
+    __shared__ float scr[kVH][kVW], scg[kVH][kVW], scb[kVH][kVW];
     __shared__ unsigned short todo[256];
     __shared__ unsigned long long wave_mask[4];
     const Geom g = a.g;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
     const int bx0 = __builtin_ctzll(cols) - kVR, bx1 = 63 - __builtin_clzll(cols) + kVR;            // tile coordinates, inclusive
     const int by0 = (m0 ? 0 : m1 ? 1 : m2 ? 2 : 3) - kVR, by1 = (m3 ? 3 : m2 ? 2 : m1 ? 1 : 0) + kVR;
     if (active) {
-        sc[ly + kVR][lx + kVR] = tc;
+        scr[ly + kVR][lx + kVR] = tc.x; scg[ly + kVR][lx + kVR] = tc.y; scb[ly + kVR][lx + kVR] = tc.z;
         sn[ly + kVR][lx + kVR] = a.nd[pix_index(g, x, y)];
     }
     for (int q = threadIdx.x; q < kVW * kVH; q += 256) {
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
         float4 hc, mom;
         int4 dbg;
         temporal_pixel(a, tx, ty, hc, mom, dbg);
-        sc[ry][rx] = hc;
+        scr[ry][rx] = hc.x; scg[ry][rx] = hc.y; scb[ry][rx] = hc.z;
         sn[ry][rx] = a.nd[pix_index(g, tx, ty)];
     }
     // ---- the short-history pixels of the tile, compacted to the first lanes (a wave with one such lane pays for the whole
@@ -138,7 +141,15 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
     if ((int)threadIdx.x < c0 + c1 + c2 + c3) {
         const int id = todo[threadIdx.x];
         const int px = id & 63, py = (id >> 6) & 3;
-        a.v_color[pix_index(g, x0 + px, y0 + py)] = variance_window_lds(sc, sn, px, py, x0 + px, y0 + py, g, v.sigma_n, v.sigma_z, id >> 8);
+        bool keep;
+        float4 o = variance_window_lds([&](int ry, int rx) { return make_float4(scr[ry][rx], scg[ry][rx], scb[ry][rx], 0.0f); },
+                                       [&](int ry, int rx) { return sn[ry][rx]; }, px, py, x0 + px, y0 + py, g, v.sigma_n, v.sigma_z, id >> 8, keep);
+        if (keep) {                                        // weights vanished (normals that break the unit-length contract): the pixel
+            float4 mom;                                    // keeps T's value, whose variance only the lane that computed it had
+            int4 dbg;
+            temporal_pixel(a, x0 + px, y0 + py, o, mom, dbg);
+        }
+        a.v_color[pix_index(g, x0 + px, y0 + py)] = o;
     }
 }
 

@@ -120,15 +120,18 @@ __device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int 
 
 constexpr int kVR = 3, kVW = 64 + 2 * kVR, kVH = 4 + 2 * kVR;      // a 64x4 tile + the 3-pixel reach of the 7x7 window: 70 x 10
 
-// Appendix A.V for the pixel (x, y) = tile pixel (lx, ly): the 49 taps read the staged colours `sc` (T's output) and `sn` (nd).
-// Tap order dx outer / dy inner, the arithmetic of variance_pixel (svgf_variance.hip): identical bits.
-__device__ __forceinline__ float4 variance_window_lds(const float4 (&sc)[kVH][kVW], const float4 (&sn)[kVH][kVW], const int lx, const int ly,
-                                                      const int x, const int y, const Geom& g, const float sigma_n, const float sigma_z, const int h)
+// Appendix A.V for the pixel (x, y) = tile pixel (lx, ly): the 49 taps read T's output (rgb) and nd of the staged 70 x 10 region
+// through `rgb(ry, rx)` / `ndz(ry, rx)` (float4 each; rgb's .w is not used).  Tap order dx outer / dy inner, the arithmetic of
+// variance_pixel (svgf_variance.hip): identical bits.  `passthrough` is set when the weights vanish (sw < 1e-10): the pixel then
+// keeps T's own value, variance included, which the caller supplies (the result's xyz are T's colour already).
+template <class Rgb, class Ndz>
+__device__ __forceinline__ float4 variance_window_lds(Rgb rgb, Ndz ndz, const int lx, const int ly, const int x, const int y, const Geom& g,
+                                                      const float sigma_n, const float sigma_z, const int h, bool& passthrough)
 {
-    const float4 c = sc[ly + kVR][lx + kVR];
-    const float4 nd = sn[ly + kVR][lx + kVR];
+    const float4 c = rgb(ly + kVR, lx + kVR);
+    const float4 nd = ndz(ly + kVR, lx + kVR);
     const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
-    const float gz = fabsf(sn[ly + kVR][x1 - x + lx + kVR].w - nd.w) + fabsf(sn[y1 - y + ly + kVR][lx + kVR].w - nd.w);
+    const float gz = fabsf(ndz(ly + kVR, x1 - x + lx + kVR).w - nd.w) + fabsf(ndz(y1 - y + ly + kVR, lx + kVR).w - nd.w);
     const float za = sigma_z * fmaxf(gz, 1e-8f);
     const bool p_zero = is_zero3(nd);
     float sw = 0.0f, scx = 0.0f, scy = 0.0f, scz = 0.0f, sl = 0.0f, sl2 = 0.0f;
@@ -141,8 +144,8 @@ __device__ __forceinline__ float4 variance_window_lds(const float4 (&sc)[kVH][kV
         for (int dy = -kVR; dy <= kVR; ++dy) {
             const int tx = x + dx, ty = y + dy;
             if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
-            const float4 tc = sc[ly + kVR + dy][lx + kVR + dx];
-            const float4 tn = sn[ly + kVR + dy][lx + kVR + dx];
+            const float4 tc = rgb(ly + kVR + dy, lx + kVR + dx);
+            const float4 tn = ndz(ly + kVR + dy, lx + kVR + dx);
             float e;
             const bool t_zero = is_zero3(tn);
             if (p_zero || t_zero) {
@@ -163,7 +166,8 @@ __device__ __forceinline__ float4 variance_window_lds(const float4 (&sc)[kVH][kV
         }
     }
     float4 o = c;
-    if (!(sw < 1e-10f)) {
+    passthrough = sw < 1e-10f;
+    if (!passthrough) {
         const float el = sl / sw, el2 = sl2 / sw;
         float var = el2 - el * el;
         if (!(var > 0.0f)) var = 0.0f;

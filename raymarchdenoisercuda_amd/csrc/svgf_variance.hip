@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void svgf_variance_tile_kernel(VarianceArgs a,
                 const int lx = id & 63, ly = (id >> 6) & 3;
                 h = id >> 8;
                 const int x = x0 + lx, y = y0 + ly;
-                const float4 o = variance_window_lds(sc, sn, lx, ly, x, y, g, a.sigma_n, a.sigma_z, h);
+                bool keep;                                         // (weights vanished: o = sc's centre, variance included)
+                const float4 o = variance_window_lds([&](int ry, int rx) { return sc[ry][rx]; }, [&](int ry, int rx) { return sn[ry][rx]; },
+                                                     lx, ly, x, y, g, a.sigma_n, a.sigma_z, h, keep);
                 a.v_color[pix_index(g, x, y)] = o;
             }
             __syncthreads();                                       // the next flagged tile restages the LDS region
