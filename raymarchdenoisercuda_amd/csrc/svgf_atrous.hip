@@ -243,45 +243,6 @@ __device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const 
     }
 }
 
-#ifndef RMD_DUAL_LONE
-#define RMD_DUAL_LONE 0           // 1: the taps only one pixel of the (A,B) pair sees (window rows 0 and 5) are weighed two at a time,
-#endif                            //    (c - dS, c + dS) of one row for ONE pixel, as a packed evaluation (measured: DESIGN.md section 4.4)
-
-// Two taps of one window row, at columns c - d*S and c + d*S, for ONE pixel: same B3 weight, same length class, so the
-// weight evaluation packs over the TAPS (lane x = the left one, lane y = the right one) with the pixel's constants broadcast.
-struct Dual { f2 l, r, g, v, nx, ny, nz, z; };
-
-template <int LANE> __device__ __forceinline__ f2 splat(f2 v) { return LANE ? f2{ v.y, v.y } : f2{ v.x, v.x }; }
-__device__ __forceinline__ f2 pk_fma_hi_clamp(f2 a, f2 b, f2 c)        // clamp01(a * b.hi + c)
-{
-    f2 r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// LANE = 0: the pixel in the x halves of the centre pairs (role A), 1: role B.  Per lane the operations of tap_single, same bits.
-template <int LANE>
-__device__ __forceinline__ void tap_dual(Acc<f2>& s, const Center<f2>& k, const CenterAux& x, const Dual& u, const float e0,
-                                         const int adx, const int ady, const float sigma_n)
-{
-    f2 d = splat<LANE>(k.nx) * u.nx;
-    d = fma_(splat<LANE>(k.ny), u.ny, d);
-    const f2 c = LANE ? pk_fma_hi_clamp(u.nz, k.nz, d) : pk_fma_lo_clamp(u.nz, k.nz, d);
-    f2 e = fma_(f2{ sigma_n, sigma_n }, log2_(c), f2{ e0, e0 });
-    const f2 dz = splat<LANE>(k.z) - u.z, dl = splat<LANE>(k.lum) - u.l;
-    const float iz = x.iz[len_class(adx, ady)], il = LANE ? k.il.y : k.il.x;
-    e.x = fma_(-fabsf(dz.x), iz, e.x);
-    e.y = fma_(-fabsf(dz.y), iz, e.y);
-    e.x = fma_(-fabsf(dl.x), il, e.x);
-    e.y = fma_(-fabsf(dl.y), il, e.y);
-    const f2 w = exp2_(e);
-    s.sw += w;
-    s.sl = fma_(w, u.l, s.sl);
-    s.sr = fma_(w, u.r, s.sr);
-    s.sg = fma_(w, u.g, s.sg);
-    s.sv = fma_(w * w, u.v, s.sv);
-}
-
 // A.A.3.  c = the centre in (lum, r, g, var) form.
 __device__ __forceinline__ float4 finish(float sw, float sl, float sr, float sg, float sv, const float4 c)
 {
@@ -350,29 +311,19 @@ __global__ __launch_bounds__(256) void atrous_direct_kernel(AtrousArgs a)
     // group is summed dx outer / dy inner and the two groups are added at the end.
     const int lone_dy = ((y / s) & 1) ? 2 : -2;
     Acc<float> acc = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, lone = acc;
-    auto tap_at = [&](Acc<float>& into, const int dx, const int dy) {
-        const int tx = x + s * dx, ty = y + s * dy;
-        if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) return;
-        const size_t ti = pix_index(g, tx, ty);
-        Tap t;
-        t.c = to_lrgv(a.in[ti]);
-        t.n = a.nd[ti];
-        const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
-        tap_single<true>(into, k, aux, t, kLogB3[adx] + kLogB3[ady], adx, ady, a.sigma_n);
-    };
-#if RMD_DUAL_LONE
-    // the stream kernel weighs the lone row as couples (c - dS, c + dS): left taps and the centre in one sum, right taps in another
-    Acc<float> lone_hi = acc;
-    tap_at(lone, -2, lone_dy); tap_at(lone, -1, lone_dy); tap_at(lone, 0, lone_dy);
-    tap_at(lone_hi, 2, lone_dy); tap_at(lone_hi, 1, lone_dy);
-    lone = Acc<float>{ lone.sw + lone_hi.sw, lone.sl + lone_hi.sl, lone.sr + lone_hi.sr, lone.sg + lone_hi.sg, lone.sv + lone_hi.sv };
-#endif
 #pragma unroll
     for (int dx = -2; dx <= 2; ++dx) {
 #pragma unroll
         for (int dy = -2; dy <= 2; ++dy) {
-            if (dy == lone_dy) { if (!RMD_DUAL_LONE) tap_at(lone, dx, dy); }
-            else tap_at(acc, dx, dy);
+            const int tx = x + s * dx, ty = y + s * dy;
+            if (tx < 0 || tx >= g.W || ty < 0 || ty >= g.H) continue;
+            const size_t ti = pix_index(g, tx, ty);
+            Tap t;
+            t.c = to_lrgv(a.in[ti]);
+            t.n = a.nd[ti];
+            const int adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+            if (dy == lone_dy) tap_single<true>(lone, k, aux, t, kLogB3[adx] + kLogB3[ady], adx, ady, a.sigma_n);
+            else               tap_single<true>(acc, k, aux, t, kLogB3[adx] + kLogB3[ady], adx, ady, a.sigma_n);
         }
     }
     a.out[i] = finish(lone.sw + acc.sw, lone.sl + acc.sl, lone.sr + acc.sr, lone.sg + acc.sg, lone.sv + acc.sv, ctr.c);
@@ -642,155 +593,6 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         const Center<f2> kAB = pack(kA, kB);
         kA = Center<float>{ kAB.nx.x, kAB.ny.x, kAB.nz.x, kAB.z.x, kAB.lum.x, kAB.il.x };   // lanes, not copies
         kB = Center<float>{ kAB.nx.y, kAB.ny.y, kAB.nz.y, kAB.z.y, kAB.lum.y, kAB.il.y };
-#if RMD_DUAL_LONE
-        // ---- lone rows weighed two taps at a time ---------------------------------------------------------------------------
-        // Window rows 1..4 are tapped by both pixels (tap_pair, as below); rows 0 and 5 by one pixel only.  Those ten taps are
-        // walked as (c - 2S, c + 2S), (c - S, c + S) of the row -- one packed evaluation per couple, lane x = the left tap --
-        // and the centre column alone, into lane x.  Per pixel: lone row = lane x (dx = -2, -1, 0) + lane y (dx = +2, +1), then
-        // + the shared rows (dx outer, dy inner); atrous_direct_kernel sums in the same order.
-        Acc<f2> sAB = { f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
-        Acc<f2> sA2 = sAB, sB2 = sAB;
-
-        bool rowv[6];
-#pragma unroll
-        for (int tr = 0; tr < 6; ++tr) {
-            const int yy = yA + (tr - 2) * S;
-            rowv[tr] = !EDGE || (yy >= 0 && yy < g.H);
-        }
-        const bool any_zero = __builtin_amdgcn_ballot_w64(xA.zero || xB.zero) != 0ull;
-        float sn;                                                      // sigma_n in a VGPR (see tap_pair)
-        asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));
-
-        // 15 groups: 0..9 the shared rows (dx = g/2 - 2, rows {1,2} | {3,4}), 10..13 the lone couples (row 0 d=2, row 5 d=2,
-        // row 0 d=1, row 5 d=1), 14 the two lone centre taps.  Reads of group g+1 are issued before group g is weighed.
-        constexpr int NG = 15;
-        auto main_off = [&](const int grp, const int q) { return rb(1 + 2 * (grp & 1) + q) + (2 * S + ((grp >> 1) - 2) * S) * 16; };
-        auto load_main = [&](const int grp, Tap (&t)[2]) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) { t[q].c = lds_f4(lds, main_off(grp, q)); t[q].n = lds_f4(lds, C::PLANE_BYTES + main_off(grp, q)); }
-        };
-        auto lone_tr = [](const int grp) { return (grp & 1) ? 5 : 0; };          // groups 10, 12: row 0; 11, 13: row 5
-        auto lone_d = [](const int grp) { return grp < 12 ? 2 : 1; };
-        // The couple's fields as register PAIRS {left tap, right tap}: ds_read2_b32 delivers exactly that (two dwords from two
-        // offsets into an aligned register pair).  Hand-issued: left to itself the compiler fetches each tap with ds_read_b128 and
-        // assembles the pairs with 16 v_mov_b32, which costs what the packing saves.  The compiler does not count these reads
-        // in its s_waitcnt bookkeeping, so weigh_lone waits for them itself (lgkmcnt counts LDS operations in order).
-        auto read2 = [&](const int addr, auto o0, auto o1) {
-            f2 v;
-            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(decltype(o0)::value), "n"(decltype(o1)::value));
-            return v;
-        };
-        auto load_dual = [&](const int grp, Dual& u) {
-            const int d = lone_d(grp);
-            const int ac = rb(lone_tr(grp)) + (2 * S - d * S) * 16, an = ac + C::PLANE_BYTES;
-            // (d = 2: the right tap is 16 S dwords from the left one, d = 1: 8 S; both fit the 8-bit offsets for S <= 8, d = 1 for S = 16)
-#define RMD_R2(F, A, K) F = (d == 2) ? read2(A, std::integral_constant<int, K>{}, std::integral_constant<int, (K + 16 * S) & 255>{}) \
-                                     : read2(A, std::integral_constant<int, K>{}, std::integral_constant<int, K + 8 * S>{})
-            RMD_R2(u.l, ac, 0); RMD_R2(u.r, ac, 1); RMD_R2(u.g, ac, 2); RMD_R2(u.v, ac, 3);
-            RMD_R2(u.nx, an, 0); RMD_R2(u.ny, an, 1); RMD_R2(u.nz, an, 2); RMD_R2(u.z, an, 3);
-#undef RMD_R2
-        };
-        // couples the 8-bit offsets of ds_read2_b32 cannot span (S = 16, d = 2) go the zero-aware way: two whole taps
-        auto dual_ok = [](const int grp) { return !(S == 16 && grp < 12); };
-        auto load_lone_taps = [&](const int grp, Tap (&t)[2]) {          // zero-aware path: the couple as two whole taps
-            const int lo = rb(lone_tr(grp)) + (2 * S - lone_d(grp) * S) * 16, hi = rb(lone_tr(grp)) + (2 * S + lone_d(grp) * S) * 16;
-            t[0].c = lds_f4(lds, lo); t[0].n = lds_f4(lds, C::PLANE_BYTES + lo);
-            t[1].c = lds_f4(lds, hi); t[1].n = lds_f4(lds, C::PLANE_BYTES + hi);
-        };
-        auto load_centres = [&](Tap (&t)[2]) {
-            t[0].c = lds_f4(lds, rb(0) + 2 * S * 16); t[0].n = lds_f4(lds, C::PLANE_BYTES + rb(0) + 2 * S * 16);
-            t[1].c = lds_f4(lds, rb(5) + 2 * S * 16); t[1].n = lds_f4(lds, C::PLANE_BYTES + rb(5) + 2 * S * 16);
-        };
-        // one pixel, one tap, accumulated into lane LANE of a pair of accumulators (plain operations on the half registers)
-        auto single_into = [&](auto za, auto lane, Acc<f2>& s2, const Center<float>& k, const CenterAux& xk, const Tap& t, const float e0,
-                               const int adx, const int ady) {
-            constexpr bool ZA = decltype(za)::value;
-            constexpr int LANE = decltype(lane)::value;
-            Acc<float> s1 = LANE ? Acc<float>{ s2.sw.y, s2.sl.y, s2.sr.y, s2.sg.y, s2.sv.y } : Acc<float>{ s2.sw.x, s2.sl.x, s2.sr.x, s2.sg.x, s2.sv.x };
-            tap_single<ZA>(s1, k, xk, t, e0, adx, ady, sn);
-            if (LANE) { s2.sw.y = s1.sw; s2.sl.y = s1.sl; s2.sr.y = s1.sr; s2.sg.y = s1.sg; s2.sv.y = s1.sv; }
-            else      { s2.sw.x = s1.sw; s2.sl.x = s1.sl; s2.sr.x = s1.sr; s2.sg.x = s1.sg; s2.sv.x = s1.sv; }
-        };
-        auto taps = [&](auto zero_aware) {
-            constexpr bool ZA = decltype(zero_aware)::value;
-            auto weigh_main = [&](const int grp, const Tap (&t)[2]) {
-                const int dx = (grp >> 1) - 2, adx = dx < 0 ? -dx : dx;
-                const bool colv = !EDGE || (x + dx * S >= 0 && x + dx * S < g.W);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int tr = 1 + 2 * (grp & 1) + q;
-                    const bool valid = !EDGE || !ZA || (colv && rowv[tr]);
-                    const int dyA = tr - 2, dyB = tr - 3;
-                    const int adyA = dyA < 0 ? -dyA : dyA, adyB = dyB < 0 ? -dyB : dyB;
-                    const float e0A = valid ? kLogB3[adx] + kLogB3[adyA] : kNegInf;
-                    const float e0B = valid ? kLogB3[adx] + kLogB3[adyB] : kNegInf;
-                    tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0A, e0B, adx, adyA, adyB, sn);
-                }
-            };
-            auto weigh_lone = [&](const int grp, const Tap (&t)[2], const Dual& u) {
-                const int tr = lone_tr(grp), d = lone_d(grp);
-                const float e0 = kLogB3[d] + kLogB3[2];
-                if (!ZA && dual_ok(grp)) {
-                    // (taps outside the frame are staged as zeros: log2(0) = -inf, weight exactly 0)
-                    // wait for this group's eight ds_read2_b32; behind them only the next group's reads are in flight:
-                    // eight (a couple), two whole taps = four, or the four of the centre group
-                    if (grp < 13 && dual_ok(grp + 1)) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                    else                               asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-                    Dual w = u;
-                    asm volatile("" : "+v"(w.l), "+v"(w.r), "+v"(w.g), "+v"(w.v), "+v"(w.nx), "+v"(w.ny), "+v"(w.nz), "+v"(w.z));   // (uses stay behind the wait)
-                    if (tr == 0) tap_dual<0>(sA2, kAB, xA, w, e0, d, 2, sn);
-                    else         tap_dual<1>(sB2, kAB, xB, w, e0, d, 2, sn);
-                } else {
-                    const bool vl = !EDGE || (rowv[tr] && x - d * S >= 0 && x - d * S < g.W);
-                    const bool vr = !EDGE || (rowv[tr] && x + d * S >= 0 && x + d * S < g.W);
-                    if (tr == 0) {
-                        single_into(zero_aware, std::integral_constant<int, 0>{}, sA2, kA, xA, t[0], vl ? e0 : kNegInf, d, 2);
-                        single_into(zero_aware, std::integral_constant<int, 1>{}, sA2, kA, xA, t[1], vr ? e0 : kNegInf, d, 2);
-                    } else {
-                        single_into(zero_aware, std::integral_constant<int, 0>{}, sB2, kB, xB, t[0], vl ? e0 : kNegInf, d, 2);
-                        single_into(zero_aware, std::integral_constant<int, 1>{}, sB2, kB, xB, t[1], vr ? e0 : kNegInf, d, 2);
-                    }
-                }
-            };
-            auto weigh_centres = [&](const Tap (&t)[2]) {
-                const bool colv = !EDGE || x < g.W;
-                const float e0 = kLogB3[0] + kLogB3[2];
-                single_into(zero_aware, std::integral_constant<int, 0>{}, sA2, kA, xA, t[0], (!EDGE || !ZA || (colv && rowv[0])) ? e0 : kNegInf, 0, 2);
-                single_into(zero_aware, std::integral_constant<int, 0>{}, sB2, kB, xB, t[1], (!EDGE || !ZA || (colv && rowv[5])) ? e0 : kNegInf, 0, 2);
-            };
-            auto load_any = [&](const int grp, Tap (&t)[2], Dual& u) {
-                if (grp < 10) load_main(grp, t);
-                else if (grp < 14) { if (ZA || !dual_ok(grp)) load_lone_taps(grp, t); else load_dual(grp, u); }
-                else load_centres(t);
-            };
-            auto weigh_any = [&](const int grp, const Tap (&t)[2], const Dual& u) {
-                if (grp < 10) weigh_main(grp, t);
-                else if (grp < 14) weigh_lone(grp, t, u);
-                else weigh_centres(t);
-            };
-            Tap t0[2], t1[2];
-            Dual u0, u1;
-            load_any(0, t0, u0);
-            static_assert(kPieces <= NG || EDGE, "one refill instruction per tap group");
-#pragma unroll
-            for (int grp = 0; grp < NG; ++grp) {
-                if (!EDGE && grp < kPieces) prefetch_piece(grp, j - 2 + C::NR, j + C::ADV);
-                if (grp & 1) { if (grp < NG - 1) load_any(grp + 1, t0, u0); weigh_any(grp, t1, u1); }
-                else         { if (grp < NG - 1) load_any(grp + 1, t1, u1); weigh_any(grp, t0, u0); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        };
-        if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
-
-        int ra = rb(2), rbb = rb(3);
-        asm volatile("" : "+v"(ra), "+v"(rbb));
-        const float4 ccA = lds_f4(lds, ra + 2 * S * 16), ccB = lds_f4(lds, rbb + 2 * S * 16);
-        outA = finish((sA2.sw.x + sA2.sw.y) + sAB.sw.x, (sA2.sl.x + sA2.sl.y) + sAB.sl.x, (sA2.sr.x + sA2.sr.y) + sAB.sr.x,
-                      (sA2.sg.x + sA2.sg.y) + sAB.sg.x, (sA2.sv.x + sA2.sv.y) + sAB.sv.x, ccA);
-        outB = finish((sB2.sw.x + sB2.sw.y) + sAB.sw.y, (sB2.sl.x + sB2.sl.y) + sAB.sl.y, (sB2.sr.x + sB2.sr.y) + sAB.sr.y,
-                      (sB2.sg.x + sB2.sg.y) + sAB.sg.y, (sB2.sv.x + sB2.sv.y) + sAB.sv.y, ccB);
-    };
-#else
         Acc<f2> sAB = { f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
         Acc<float> sA = { 0, 0, 0, 0, 0 }, sB = sA;      // rows only one of the two pixels taps (tr = 0 / tr = 5)
 
@@ -875,7 +677,6 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         outA = finish(sA.sw + sAB.sw.x, sA.sl + sAB.sl.x, sA.sr + sAB.sr.x, sA.sg + sAB.sg.x, sA.sv + sAB.sv.x, ccA);
         outB = finish(sB.sw + sAB.sw.y, sB.sl + sAB.sl.y, sB.sr + sAB.sr.y, sB.sg + sAB.sg.y, sB.sv + sAB.sv.y, ccB);
     };
-#endif
     // The two output pixels of step j are written AFTER the ring refill of the step: the refill has to
     // wait for the prefetch loads (vmcnt), and stores issued before it would be waited for as well.
     auto write_out = [&](const int j) {
