@@ -26,6 +26,7 @@ FuncVector& registeredFuncs();   // function-local static: registration order no
 // reference's tests lack.
 void expect(bool cond, const std::string& what);
 
-int test(std::string wildcard = ".*");   // returns the number of failed tests
+void test(std::string wildcard = ".*");   // reference include/test.h:22: returns nothing
+int testFailures();                       // bodies that threw since the process started (the CLI's exit status)
 
 #endif

@@ -28,9 +28,10 @@ private:
 
 public:
     CudaVector() = default;
-    explicit CudaVector(size_t size) : size_p(size) { rmdCheck(rmd_malloc((void**)&data_p, size * sizeof(T)), "CudaVector"); }
+    // (not `explicit`, like the reference's constructors at include/vector.h:119-130: a size or a host vector converts)
+    CudaVector(size_t size) : size_p(size) { rmdCheck(rmd_malloc((void**)&data_p, size * sizeof(T)), "CudaVector"); }
     CudaVector(const T* hostData, size_t size) : CudaVector(size) { copyFrom(hostData, size); }   // reference :124-127
-    explicit CudaVector(const CpuVector<T>& v) : CudaVector(v.data(), v.size()) {}                // reference :130
+    CudaVector(const CpuVector<T>& v) : CudaVector(v.data(), v.size()) {}                         // reference :130
     // non-owning view of `size` elements of DEVICE memory (the destructor leaves them alone)
     static CudaVector wrap(T* devicePtr, size_t size)
     {

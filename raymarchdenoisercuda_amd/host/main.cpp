@@ -50,7 +50,6 @@ int main(int argc, char* argv[])
     const Request req = parse(std::vector<std::string>(argv + 1, argv + argc));
     for (const std::string& u : req.unknown) std::fprintf(stderr, "Unknown option: %s\n", u.c_str());
     if (req.help || (req.labels.empty() && req.unknown.empty())) return help(argv[0]);
-    int failed = 0;
-    for (const std::string& label : req.labels) failed += test(label);
-    return failed ? 2 : 0;
+    for (const std::string& label : req.labels) test(label);
+    return testFailures() ? 2 : 0;
 }

@@ -40,7 +40,10 @@ void expect(bool cond, const std::string& what)
     if (!cond) throw std::runtime_error("expectation failed: " + what);
 }
 
-int test(std::string wildcard)
+static int g_failed = 0;
+int testFailures() { return g_failed; }
+
+void test(std::string wildcard)
 {
     FuncVector& funcs = registeredFuncs();
     printf("----------------------------------------------------------\n");
@@ -49,7 +52,6 @@ int test(std::string wildcard)
     printf("\n----------------------------------------------------------\n");
 
     std::regex pattern(wildcard);
-    int failed = 0;
     for (auto& f : funcs) {
         if (!std::regex_match(f.first, pattern)) continue;
         try {
@@ -60,14 +62,13 @@ int test(std::string wildcard)
             printf("Passed with %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
         } catch (const std::runtime_error& e) {
             printf("Fail with %s\n", e.what());
-            ++failed;
+            ++g_failed;
         } catch (...) {
             printf("Failed\n");
-            ++failed;
+            ++g_failed;
         }
         printf("----------------------------------------------------------\n");
     }
-    return failed;
 }
 
 // ---- SHA-256 (FIPS 180-4) for the known-answer checks ---------------------------------------

@@ -263,24 +263,27 @@ class SvgfDenoiser:
             s_ptr = _stream_ptr(torch.cuda.current_stream() if stream is None else stream)
             mid = frame_mid_exchange(self.params)[0]
             p = self.params
+            # the history-ready event only where somebody waits for it (a row-strip deployment): an event record between two
+            # launches costs ~6 us of idle GPU on this stack (tools/frame_gaps.py)
+            ev_hist = self._ev_hist if hooks is not None and hasattr(hooks, "hist_ready") else None
             check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(p), row0, row1, s_ptr))
             if mid < 0:
-                check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist))
+                check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist))
                 if hooks is not None and hasattr(hooks, "hist_ready"):
-                    hooks.hist_ready(self._ev_hist)
+                    hooks.hist_ready(ev_hist)
             else:
                 hist_in_head = p.hist_iteration <= mid
-                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist, ATROUS_HEAD))
+                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist, ATROUS_HEAD))
                 if hooks is not None and hasattr(hooks, "mid_ready"):
                     hooks.mid_ready(self.iteration_plane(mid, out))
                 if hist_in_head and hooks is not None and hasattr(hooks, "hist_ready"):
-                    hooks.hist_ready(self._ev_hist)
-                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist, ATROUS_INTERIOR))
+                    hooks.hist_ready(ev_hist)
+                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist, ATROUS_INTERIOR))
                 if hooks is not None and hasattr(hooks, "mid_wait"):
                     hooks.mid_wait()
-                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, self._ev_hist, ATROUS_TAIL))
+                check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist, ATROUS_TAIL))
                 if not hist_in_head and hooks is not None and hasattr(hooks, "hist_ready"):
-                    hooks.hist_ready(self._ev_hist)
+                    hooks.hist_ready(ev_hist)
         else:
             if frame_mid_exchange(self.params)[0] >= 0:
                 raise ValueError("exchange_iteration >= 0 needs the serial (single-stream) frame: pipelined=False")

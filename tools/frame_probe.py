@@ -19,6 +19,7 @@ PAN = tuple(float(v) for v in os.environ.get("PROBE_PAN", "1.25,-0.5").split(","
 p = rmd.default_params()
 p.max_motion_rows = 8
 p.tv_workgroups = int(os.environ.get("PROBE_TV_WG", 0))
+p.hist_iteration = int(os.environ.get("PROBE_HIST_IT", 0))
 den = rmd.SvgfDenoiser(W, H, params=p, pipelined=os.environ.get("PROBE_PIPELINE", "0") == "1")
 inputs = [rmd.svgf.synth_gbuffer(W, H, f, pan=PAN) for f in range(8)]
 for f in range(8):
