@@ -154,8 +154,8 @@ typedef struct rmd_svgf_params {
                                    2*(2^(X+1) + ... + 2^(iterations-1)) rows beyond them from rank +-1 (ONE neighbour exchange
                                    per frame); T, V and the iterations in front of X then run on that many fewer rows.
                                    Whole-frame calls are unaffected.  Strips drive the frame in parts
-                                   (rmd_svgf_frame_atrous_part) so that iteration X+1 starts on its interior rows while the
-                                   halo travels                                                                 */
+                                   (rmd_svgf_frame_atrous_part): iteration X's boundary rows first, its interior rows
+                                   while the halo travels                                                       */
 } rmd_svgf_params;
 
 void rmd_svgf_default_params(rmd_svgf_params* p);
@@ -225,12 +225,12 @@ int rmd_svgf_frame_tv(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, in
 int rmd_svgf_frame_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
                           void* history_ready_event);
 /* The a-trous iterations of a strip whose params name an exchange_iteration X, in the three parts the exchange cuts them into:
- *   RMD_ATROUS_HEAD      iterations 0..X (X on rows [row0,row1) only).  Then the caller starts the neighbour exchange of
- *                        the plane rmd_svgf_frame_iteration_plane(f, p, X) -- rows per side: rmd_svgf_frame_mid_exchange --
- *                        on another stream, ordered behind an event recorded here;
- *   RMD_ATROUS_INTERIOR  iteration X+1 on the rows that tap none of the halo (at least 2*2^(X+1) rows inside every strip
- *                        edge that is not a frame edge): runs while the halo travels;
- *   RMD_ATROUS_TAIL      after the exchange has completed: iteration X+1 on the remaining (boundary) rows, then X+2 ...
+ *   RMD_ATROUS_HEAD      iterations 0..X-1, then iteration X on the BOUNDARY rows of the strip: the rows rank +-1 is waiting
+ *                        for (rmd_svgf_frame_mid_exchange()[1] rows at each end that is not a frame edge).  Then the caller
+ *                        starts the neighbour exchange of the plane rmd_svgf_frame_iteration_plane(f, p, X) on another
+ *                        stream, ordered behind an event recorded here;
+ *   RMD_ATROUS_INTERIOR  iteration X on the remaining rows of the strip: runs while the halo travels;
+ *   RMD_ATROUS_TAIL      after the exchange has completed: iterations X+1 ... (whole launches, halo rows included)
  *   RMD_ATROUS_ALL       everything in order (= rmd_svgf_frame_atrous; complete only where no halo is needed: whole frames,
  *                        or exchange_iteration = -1).
  * Same kernels on other row ranges: bit-identical to the unsharded frame (tests/test_svgf_gpu.py, test_sharding_*). */
@@ -263,9 +263,9 @@ int  rmd_svgf_context_reset_history(rmd_svgf_context* ctx, void* stream);
 int  rmd_svgf_context_denoise(rmd_svgf_context* ctx, const rmd_svgf_params* p,
                               const float* color, const float* nd, const float* motion,
                               const float* prev_nd, float* out, int row0, int row1, void* stream);
-/* The same frame in the parts of rmd_svgf_frame_atrous_part: RMD_ATROUS_HEAD runs T + V + iterations 0..X,
- * RMD_ATROUS_INTERIOR / RMD_ATROUS_TAIL the rest; the history planes rotate with the TAIL part.  Between HEAD and TAIL the
- * caller exchanges the rows of rmd_svgf_context_mid_plane with rank +-1 (rmd_mid_exchange). */
+/* The same frame in the parts of rmd_svgf_frame_atrous_part: RMD_ATROUS_HEAD runs T + V + iterations 0..X-1 + the boundary
+ * rows of X, RMD_ATROUS_INTERIOR / RMD_ATROUS_TAIL the rest; the history planes rotate with the TAIL part.  Between HEAD and
+ * TAIL the caller exchanges the rows of rmd_svgf_context_mid_plane with rank +-1 (rmd_mid_exchange). */
 int  rmd_svgf_context_denoise_part(rmd_svgf_context* ctx, const rmd_svgf_params* p,
                                    const float* color, const float* nd, const float* motion,
                                    const float* prev_nd, float* out, int row0, int row1, void* stream, int part);

@@ -7,7 +7,8 @@
 //       stream and then the neighbour history-halo exchange (RCCL over xGMI; ranks that share a device
 //       -- a rehearsal on one GPU -- copy the rows device-to-device by the same plan).  With
 //       params.exchange_iteration = X >= 0 the frame additionally exchanges AX's halo rows in its middle
-//       (on a second stream per rank, beside the interior rows of A(X+1)) and runs T, V, A0..AX on fewer rows.
+//       (AX's boundary rows first; they travel on a second stream per rank beside AX's interior rows) and runs T, V,
+//       A0..AX on fewer rows.
 // A multi-PROCESS host (one rank per process) uses StripPlan + SvgfContext + rmd_comm_create /
 // rmd_halo_exchange directly: INTEGRATION.md shows the loop.
 #ifndef RMD_STRIPS_H
@@ -65,7 +66,7 @@ public:
         StripPlan plan;
         std::unique_ptr<SvgfContext> ctx;
         void* stream = nullptr;
-        void* commStream = nullptr;                  // carries the mid-frame exchange beside the interior rows of the next iteration
+        void* commStream = nullptr;                  // carries the mid-frame exchange beside the interior rows of the exchanged iteration
         void* headDone = nullptr; void* midDone = nullptr;   // events
     };
     std::vector<Rank> ranks;
@@ -115,8 +116,8 @@ public:
                 r.ctx->denoise(params_, color[k], nd[k], motion[k], prevNd[k], out[k], r.plan.row0, r.plan.row1, r.stream);
             }
         } else {
-            // One neighbour exchange inside the frame: every rank's T + V + A0..AX, then AX's halo rows travel on the comm
-            // streams while A(X+1) runs on its interior rows; its boundary rows and the later iterations wait for the halo.
+            // One neighbour exchange inside the frame: every rank's T + V + A0..A(X-1) + the boundary rows of AX, which then
+            // travel on the comm streams while AX runs on its interior rows; A(X+1) ... wait for the halo.
             auto part = [&](int k, int which) {
                 Rank& r = ranks[k];
                 rmdCheck(rmd_set_device(r.device), "NodeDenoiser::denoise(set device)");

@@ -158,12 +158,13 @@ void orc_weighted_filter(const uint8_t* render, uint8_t* denoised, uint8_t* buf0
                         if (mode == RMD_FILTER_WAVELET) k = spline[dx < 0 ? -dx : dx] * spline[dy < 0 ? -dy : dy];
                         else e = (float)(dx * dx + dy * dy) * is_s;
                         if (mode != RMD_FILTER_GAUSSIAN) {
-                            e += dist2_u8(in + i, in + t) * is_c;
-                            if (albedo) e += dist2_u8(albedo + i, albedo + t) * is_a;
-                            if (normal) e += dist2_u8(normal + i, normal + t) * is_n;
+                            /* each term one fused multiply-add (a single rounding; the squared distances are exact) */
+                            e = fmaf(dist2_u8(in + i, in + t), is_c, e);
+                            if (albedo) e = fmaf(dist2_u8(albedo + i, albedo + t), is_a, e);
+                            if (normal) e = fmaf(dist2_u8(normal + i, normal + t), is_n, e);
                         }
                         float w = k * expf(-e);
-                        sr += w * (float)in[t]; sg += w * (float)in[t + 1]; sb += w * (float)in[t + 2];
+                        sr = fmaf(w, (float)in[t], sr); sg = fmaf(w, (float)in[t + 1], sg); sb = fmaf(w, (float)in[t + 2], sb);
                         sw += w;
                     }
                 out[i] = (uint8_t)(sr / sw); out[i + 1] = (uint8_t)(sg / sw); out[i + 2] = (uint8_t)(sb / sw); out[i + 3] = 0;

@@ -205,30 +205,30 @@ int rmd_svgf_frame_atrous_part(const rmd_svgf_frame_desc* f, const rmd_svgf_para
         float* out;
         atrous_route(f, p, i, &in, &out);
         const int a0 = clampi(row0 - r.atrous[i], 0, H), a1 = clampi(row1 + r.atrous[i], 0, H);
-        // Rows of iteration mid+1 that tap nothing of the exchanged halo: at least 2 steps inside the strip on every side that
-        // HAS rows beyond it (a strip edge that is the frame edge has no halo).  They can run while the halo travels.
-        int lo = a0, hi = a1;
-        if (r.mid >= 0 && i == r.mid + 1) {
-            const int reach_i = 2 * (1 << i);
-            if (row0 > 0) lo = clampi(row0 + reach_i, a0, a1);
-            if (row1 < H) hi = clampi(row1 - reach_i, lo, a1);
+        // The exchanged iteration (mid) is computed on the strip's own rows [a0,a1) = [row0,row1), BOUNDARY FIRST: the mid_rows
+        // rows at each end that has a neighbour are what that neighbour is waiting for; they go out while the interior rows
+        // are computed.  (Cutting the iteration BEHIND the exchange into interior + boundary instead was measured: at step 16
+        // the two 32-row launches cost 30 us and the 476-row interior as much as the whole strip)
+        int lo = a0, hi = a1;                       // interior of iteration mid
+        if (r.mid >= 0 && i == r.mid) {
+            if (row0 > 0) lo = clampi(row0 + r.mid_rows, a0, a1);
+            if (row1 < H) hi = clampi(row1 - r.mid_rows, lo, a1);
         }
         // which row ranges of this iteration the requested part runs
         int ranges[2][2], nr = 0;
-        const bool head = r.mid < 0 || i <= r.mid;
-        if (part == RMD_ATROUS_ALL || (part == RMD_ATROUS_HEAD && head) || (part == RMD_ATROUS_TAIL && !head && i != r.mid + 1)) {
+        const bool before = r.mid < 0 || i < r.mid, at = r.mid >= 0 && i == r.mid;
+        if (part == RMD_ATROUS_ALL || (part == RMD_ATROUS_HEAD && before) || (part == RMD_ATROUS_TAIL && !before && !at)) {
             ranges[nr][0] = a0; ranges[nr][1] = a1; ++nr;
-        } else if (part == RMD_ATROUS_INTERIOR && i == r.mid + 1) {
+        } else if (part == RMD_ATROUS_HEAD && at) {
+            if (lo > a0) { ranges[nr][0] = a0; ranges[nr][1] = lo; ++nr; }
+            if (a1 > hi) { ranges[nr][0] = hi; ranges[nr][1] = a1; ++nr; }
+        } else if (part == RMD_ATROUS_INTERIOR && at) {
             if (hi > lo) { ranges[nr][0] = lo; ranges[nr][1] = hi; ++nr; }
-        } else if (part == RMD_ATROUS_TAIL && i == r.mid + 1) {
-            if (hi > lo) {
-                if (lo > a0) { ranges[nr][0] = a0; ranges[nr][1] = lo; ++nr; }
-                if (a1 > hi) { ranges[nr][0] = hi; ranges[nr][1] = a1; ++nr; }
-            } else { ranges[nr][0] = a0; ranges[nr][1] = a1; ++nr; }      // strip too short for an interior: everything waits
         }
         for (int q = 0; q < nr; ++q)
             if (int e = rmd_svgf_atrous(f, p, i, in, out, ranges[q][0], ranges[q][1], stream)) return e;
         if (nr == 0) continue;
+        if (at && part == RMD_ATROUS_HEAD && hi > lo) continue;        // (iteration mid is complete only after its interior part)
         if (i == n - 1 && i == p->hist_iteration && f->hist_color_out != out) {
             const size_t off = (size_t)(a0 - f->buf_row0) * f->width * 4;
             RMD_HIP(hipMemcpyAsync(f->hist_color_out + off, out + off, (size_t)(a1 - a0) * f->width * 16,
@@ -236,7 +236,7 @@ int rmd_svgf_frame_atrous_part(const rmd_svgf_frame_desc* f, const rmd_svgf_para
         }
         // next frame's history (hist_color_out, and t_moments since T ran before) is complete here -- up to the rows a
         // mid-frame exchange still has to deliver when hist_iteration IS the exchanged iteration
-        if (i == p->hist_iteration && history_ready_event && part != RMD_ATROUS_INTERIOR)
+        if (i == p->hist_iteration && history_ready_event)
             RMD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(history_ready_event), as_stream(stream)));
     }
     return RMD_OK;

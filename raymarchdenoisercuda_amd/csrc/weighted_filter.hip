@@ -37,7 +37,7 @@ struct WeightedArgs {
 __device__ __forceinline__ float dist2(uchar4 a, uchar4 b)
 {
     const float dx = (float)a.x - (float)b.x, dy = (float)a.y - (float)b.y, dz = (float)a.z - (float)b.z;
-    return dx * dx + dy * dy + dz * dz;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));          // exact (integers < 2^24), whatever the grouping
 }
 
 // One tap: weight and accumulation (tap order dx outer / dy inner is the caller's)
@@ -50,12 +50,13 @@ __device__ __forceinline__ void weighted_tap(const WeightedArgs& a, const int dx
     if (a.mode == RMD_FILTER_WAVELET) k = spline[abs(dx)] * spline[abs(dy)];
     else e = (float)(dx * dx + dy * dy) * a.inv2s_space;
     if (a.mode != RMD_FILTER_GAUSSIAN) {
-        e += dist2(cp, ct) * a.inv2s_color;
-        if (a.albedo) e += dist2(ap, at) * a.inv2s_albedo;
-        if (a.normal) e += dist2(np, nt) * a.inv2s_normal;
+        // fused multiply-adds, as the oracle states them (oracle/box_oracle.c orc_weighted_filter)
+        e = __builtin_fmaf(dist2(cp, ct), a.inv2s_color, e);
+        if (a.albedo) e = __builtin_fmaf(dist2(ap, at), a.inv2s_albedo, e);
+        if (a.normal) e = __builtin_fmaf(dist2(np, nt), a.inv2s_normal, e);
     }
     const float w = k * __expf(-e);
-    sr += w * (float)ct.x; sg += w * (float)ct.y; sb += w * (float)ct.z;
+    sr = __builtin_fmaf(w, (float)ct.x, sr); sg = __builtin_fmaf(w, (float)ct.y, sg); sb = __builtin_fmaf(w, (float)ct.z, sb);
     sw += w;
 }
 

@@ -193,8 +193,9 @@ class ShardedDenoiser:
     ordered by events, underneath the a-trous iterations --
       * next frame's HISTORY halo right after the history iteration (A_0) has been queued, awaited in front of the
         next frame's temporal pass;
-      * with params.exchange_iteration = X >= 0, the MID-FRAME halo of iteration X's output right after X has been
-        queued; iteration X+1 meanwhile runs on its interior rows and takes its boundary rows once the halo is in.
+      * with params.exchange_iteration = X >= 0, the MID-FRAME halo of iteration X's output: X runs on its boundary rows
+        first (what the neighbours wait for), they travel while X's interior rows are computed, and X+1 starts on the
+        whole strip once the halo is in.
     pipelined=True is the older two-stream form (T+V of frame k+1 beside the a-trous iterations of frame k; the history
     halo completed lazily on the T+V stream); it does not support exchange_iteration.
     """

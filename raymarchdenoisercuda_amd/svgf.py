@@ -247,8 +247,9 @@ class SvgfDenoiser:
         `hooks` (serial form; a row-strip deployment, sharding.ShardedDenoiser) may have
           hist_ready(event)  called on the host once the launches that complete next frame's history planes are queued;
                              `event` (a hipEvent_t) is recorded behind them on the frame's stream
-          mid_ready(plane)   params.exchange_iteration = X >= 0: called after iterations 0..X are queued, with X's output plane;
-                             the hook starts the neighbour exchange of its halo rows on another stream
+          mid_ready(plane)   params.exchange_iteration = X >= 0: called after iterations 0..X-1 and the BOUNDARY rows of X are
+                             queued, with X's output plane; the hook starts the neighbour exchange of those rows on another
+                             stream (X's interior rows are queued next and run meanwhile)
           mid_wait()         called before the launches that read that halo (makes the frame's stream wait for it)."""
         if out is None:
             out = torch.empty_like(color)
@@ -272,17 +273,19 @@ class SvgfDenoiser:
                 if hooks is not None and hasattr(hooks, "hist_ready"):
                     hooks.hist_ready(ev_hist)
             else:
-                hist_in_head = p.hist_iteration <= mid
+                hist_in_head = p.hist_iteration < mid           # (the exchanged iteration itself completes with its INTERIOR part)
                 check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist, ATROUS_HEAD))
                 if hooks is not None and hasattr(hooks, "mid_ready"):
                     hooks.mid_ready(self.iteration_plane(mid, out))
                 if hist_in_head and hooks is not None and hasattr(hooks, "hist_ready"):
                     hooks.hist_ready(ev_hist)
                 check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist, ATROUS_INTERIOR))
+                if p.hist_iteration == mid and hooks is not None and hasattr(hooks, "hist_ready"):
+                    hooks.hist_ready(ev_hist)
                 if hooks is not None and hasattr(hooks, "mid_wait"):
                     hooks.mid_wait()
                 check(lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist, ATROUS_TAIL))
-                if not hist_in_head and hooks is not None and hasattr(hooks, "hist_ready"):
+                if p.hist_iteration > mid and hooks is not None and hasattr(hooks, "hist_ready"):
                     hooks.hist_ready(ev_hist)
         else:
             if frame_mid_exchange(self.params)[0] >= 0:
