@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A "step" is one frame: T + V + 5 x A over the whole frame (7 kernel launches), inputs resident in
+A "step" is one frame: T + V (one launch) + 5 x A over the whole frame (6 kernel launches), inputs resident in
 HBM before the timed region (all W+K frames of G-buffer are pre-generated on the device).
   N = 1 : BASELINE.json configs[2], 3840x2160 synthetic G-buffer + radiance, fp32.
   N > 1 : BASELINE.json configs[3], the fixed 7680x4320 (8K) frame cut into N row strips of 4320/N
@@ -33,8 +33,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 ATROUS_BYTES_PER_PX = 48       # per iteration: color 16 + nd 16 read, color 16 written
 FULL_BYTES_PER_PX = 424        # T 120 + V 64 + 5 x 48, every pass priced on its own
-MOVED_BYTES_PER_PX = 360       # what rmd_svgf_frame moves: T 88 read + 32 written (v_color, t_moments; t_color only in the
-                               # ~2 % of tiles it flags for V), V ~0 (flagged tiles only), 5 x 48
+MOVED_BYTES_PER_PX = 360       # what rmd_svgf_frame moves: T+V 88 read + 32 written (v_color, t_moments; V's windows are recomputed
+                               # in the T workgroup, no t_color plane), 5 x 48
 MAX_RESIDENT = 64              # pre-generated G-buffer frames kept in HBM
 
 
@@ -454,7 +454,7 @@ def main():
         "higher_is_better": True, "scaling": "weak" if world == 1 else "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": workload, "frame": [width, height], "rows_per_gpu": rows_out,
-                   "parallelism": f"row-strip x{world}", "passes": "T + V + 5 x A (7 launches/frame)",
+                   "parallelism": f"row-strip x{world}", "passes": "T+V (one launch) + 5 x A (6 launches/frame)",
                    "frame_pipelining": "T+V of frame k+1 overlap A1..A4 of frame k (2 streams)" if pipelined else "none"},
         # 424 B/px is SURVEY §8(d)'s per-pass algorithmic count; with V's pass-through copy fused into T the
         # frame actually moves 360 B/px, which is the figure to hold against the HBM peak

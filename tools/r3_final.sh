@@ -11,5 +11,5 @@ cat $OUT/gaps.txt
 RMD_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 20 --warmup 4 --no-other-sizes > $OUT/bench_n2_gloo.json 2> $OUT/bench_n2_gloo.err || { tail -5 $OUT/bench_n2_gloo.err; exit 1; }
 python3 -c "
 import json
-d=json.load(open('$OUT/bench_n2_gloo.json'))
+d=[json.loads(l) for l in open('$OUT/bench_n2_gloo.json') if l.startswith('{')][0]
 print('N=2 (gloo, one GPU shared):', d['value'], d['ms_per_step'], d['config']['exchanges'], d['halo_bytes_per_frame_rank0'])"
