@@ -334,6 +334,10 @@ int rmd_mid_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, fl
 /* Explicit steps on communicator comm_index of c (tests: a loop-back exchange on one GPU). */
 int rmd_halo_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
                             int width, float* hist_color, float* hist_moments, void* stream);
+/* The same with all three planes a step may name: planes[RMD_PLANE_HIST_COLOR], [RMD_PLANE_HIST_MOMENTS], [RMD_PLANE_MID]
+ * (entries no step names may be NULL). */
+int rmd_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
+                       int width, float* const planes[3], void* stream);
 
 /* ---- 8-bit <-> float plane conversion --------------------------------- */
 /* uchar4 -> float4, c/255; optional per-pixel renormalisation of xyz (for normals). */

@@ -128,6 +128,7 @@ SYMBOLS = {
     "rmd_halo_exchange": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, _P, _P, _P]),
     "rmd_halo_exchange_all": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "rmd_halo_exchange_steps": (C.c_int, [_P, C.c_int, C.POINTER(HaloStep), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "rmd_exchange_steps": (C.c_int, [_P, C.c_int, C.POINTER(HaloStep), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P), _P]),
     "rmd_convert_u8_to_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_float, _P]),
     "rmd_convert_f32_to_u8": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "rmd_demodulate": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_float, _P]),

@@ -261,7 +261,8 @@ static int post_steps(Rccl* r, ncclComm_t comm, const rmd_halo_step* steps, int 
 {
     for (int i = 0; i < n; ++i) {
         const rmd_halo_step& s = steps[i];
-        float* plane = s.plane == RMD_PLANE_MID ? mid_plane : (s.plane == 0 ? hist_color : hist_moments);
+        if (s.plane < RMD_PLANE_HIST_COLOR || s.plane > RMD_PLANE_MID) return fail(RMD_E_PARAM, "rmd_halo_exchange: plane index %d", s.plane);
+        float* plane = s.plane == RMD_PLANE_MID ? mid_plane : (s.plane == RMD_PLANE_HIST_COLOR ? hist_color : hist_moments);
         if (!plane) return fail(RMD_E_NULL, "rmd_halo_exchange: plane %d is NULL", s.plane);
         if (s.row_lo < buf_row0 || s.row_hi > buf_row0 + buf_rows || s.row_lo >= s.row_hi)
             return fail(RMD_E_ROWS, "rmd_halo_exchange: rows [%d,%d) outside the planes [%d,%d)", s.row_lo, s.row_hi, buf_row0, buf_row0 + buf_rows);
@@ -273,21 +274,29 @@ static int post_steps(Rccl* r, ncclComm_t comm, const rmd_halo_step* steps, int 
     return RMD_OK;
 }
 
-int rmd_halo_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
-                            int width, float* hist_color, float* hist_moments, void* stream)
+int rmd_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
+                       int width, float* const planes[3], void* stream)
 {
     if (!c) return fail(RMD_E_NULL, "rmd_halo_exchange: communicator is NULL");
     if (comm_index < 0 || comm_index >= (int)c->comms.size()) return fail(RMD_E_PARAM, "rmd_halo_exchange: communicator index %d", comm_index);
     if (n_steps == 0) return RMD_OK;
-    if (!steps || width <= 0) return fail(RMD_E_NULL, "rmd_halo_exchange: steps is NULL or width <= 0");
+    if (!steps || !planes || width <= 0) return fail(RMD_E_NULL, "rmd_halo_exchange: steps / planes is NULL or width <= 0");
     Rccl* r = rccl();
     if (!r) return fail(RMD_E_COMM, "rmd_halo_exchange: librccl.so not found");
     RMD_NCCL(r, r->GroupStart());
-    const int e = post_steps(r, c->comms[comm_index], steps, n_steps, buf_row0, buf_rows, width, hist_color, hist_moments, as_stream(stream));
+    const int e = post_steps(r, c->comms[comm_index], steps, n_steps, buf_row0, buf_rows, width, planes[RMD_PLANE_HIST_COLOR],
+                             planes[RMD_PLANE_HIST_MOMENTS], as_stream(stream), planes[RMD_PLANE_MID]);
     const int g = r->GroupEnd();
     if (e) return e;
     if (g != kNcclSuccess) return nccl_fail(r, g, "ncclGroupEnd");
     return RMD_OK;
+}
+
+int rmd_halo_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
+                            int width, float* hist_color, float* hist_moments, void* stream)
+{
+    float* const planes[3] = { hist_color, hist_moments, nullptr };
+    return rmd_exchange_steps(c, comm_index, steps, n_steps, buf_row0, buf_rows, width, planes, stream);
 }
 
 int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* hist_color, float* hist_moments, void* stream)

@@ -127,3 +127,43 @@ def test_pipelined_row_strips_over_torch_distributed(cuda):
         p.join(300)
         assert p.exitcode == 0
     assert [result.get(r) for r in range(world)] == [True] * world
+
+
+@pytest.mark.parametrize("stats", [False, True])
+def test_scratch_planes_poisoned_with_nan_change_nothing(rmd, cuda, stats):
+    """t_color is scratch inside rmd_svgf_frame (with statistics: the separate T and V launches write all of it; without:
+    T and V run as one launch and never touch it), v_color and the ping planes are written before they are read: poisoning
+    all of them with NaN before every frame must leave the output and the history finite and bit-equal to an unpoisoned run."""
+    width, height, frames = 333, 150, 4
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    dens = [rmd.SvgfDenoiser(width, height, params=p, collect_stats=stats) for _ in range(2)]
+    for f in range(frames):
+        c, nd, m = rmd.svgf.synth_gbuffer(width, height, f)
+        for t in (dens[1].t_color, dens[1].v_color, dens[1].ping[0], dens[1].ping[1]):
+            t.fill_(float("nan"))
+        outs = [den.denoise(c, nd, m, torch.full_like(c, float("nan"))) for den in dens]
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[1]).all() and torch.equal(outs[0], outs[1]), f"frame {f}"
+        for a, b in zip(dens[0].history(), dens[1].history()):
+            assert torch.isfinite(b).all() and torch.equal(a, b), f"frame {f} history"
+
+
+def test_frame_parts_are_refused_without_an_exchange_iteration(rmd, cuda):
+    import ctypes as C
+    width, height = 128, 64
+    p = rmd.default_params()
+    den = rmd.SvgfDenoiser(width, height, params=p)
+    c, nd, m = rmd.svgf.synth_gbuffer(width, height, 0)
+    d = den.describe(c, nd, m, torch.empty_like(c))
+    for part in (rmd.svgf.ATROUS_HEAD, rmd.svgf.ATROUS_INTERIOR, rmd.svgf.ATROUS_TAIL):
+        assert rmd.lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), 0, height, None, None, part) == -3      # RMD_E_PARAM
+    assert rmd.lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), 0, height, None, None, 7) == -3
+    p.exchange_iteration = 4                                   # the last iteration has nothing behind it
+    assert rmd.lib.rmd_svgf_frame_atrous_part(C.byref(d), C.byref(p), 0, height, None, None, rmd.svgf.ATROUS_ALL) == -3
+    p.exchange_iteration = 3                                   # a whole frame needs no halo: the parts in order ARE the frame
+    den2 = rmd.SvgfDenoiser(width, height, params=p)
+    want = rmd.SvgfDenoiser(width, height, params=rmd.default_params()).denoise(c, nd, m)
+    got = den2.denoise(c, nd, m)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)

@@ -119,4 +119,14 @@ def test_rccl_loopback_exchange_on_one_gpu(rmd, cuda):
     assert torch.equal(hc, want_c) and torch.equal(hm, want_m)
     bad = (HaloStep * 1)(HaloStep(HaloStep.SEND, 0, 90, 95, 0))
     assert lib.rmd_halo_exchange_steps(comm, 0, bad, 1, 100, rows, width, hc.data_ptr(), hm.data_ptr(), stream) == -5
+    # the mid-frame plane through the same group: rows [0,4) of an a-trous plane to self into rows [36,40)
+    mid = torch.rand((rows, width, 4), device="cuda", generator=g)
+    want_mid = mid.clone()
+    want_mid[36:40] = mid[0:4]
+    planes = (C.c_void_p * 3)(None, None, mid.data_ptr())
+    msteps = (HaloStep * 2)(HaloStep(HaloStep.RECV, HaloStep.PLANE_MID, 136, 140, 0), HaloStep(HaloStep.SEND, HaloStep.PLANE_MID, 100, 104, 0))
+    rmd.check(lib.rmd_exchange_steps(comm, 0, msteps, 2, 100, rows, width, planes, stream))
+    torch.cuda.synchronize()
+    assert torch.equal(mid, want_mid)
+    assert lib.rmd_exchange_steps(comm, 0, (HaloStep * 1)(HaloStep(HaloStep.SEND, 5, 100, 104, 0)), 1, 100, rows, width, planes, stream) == -3
     rmd.check(lib.rmd_comm_destroy(comm))
