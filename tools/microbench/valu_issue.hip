@@ -18,10 +18,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define REP8(X)  X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define REP16x8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
-enum { FMA, MUL, ADD, PKFMA, PKMUL, PKADD, EXP, LOG, RCP, FMA_MOD, FMA_LIT, FMA_SGPR, MIX_TAP, FMA_EXP_1_4, PKFMA_OPSEL, MAX3, MED3, FMA_DPP, CVT, SUB, MAXF, MINF, FMAC, MOV, CNDMASK, FMA_CLAMP, MUL_CLAMP, FMA_INL, ADDU, LSHL, ANDB, MADU24, FMAMK, MUL_SGPR, FMA_2DIFF, N_MODES };
+enum { FMA, MUL, ADD, PKFMA, PKMUL, PKADD, EXP, LOG, RCP, FMA_MOD, FMA_LIT, FMA_SGPR, MIX_TAP, FMA_EXP_1_4, PKFMA_OPSEL, MAX3, MED3, FMA_DPP, CVT, SUB, MAXF, MINF, FMAC, MOV, CNDMASK, FMA_CLAMP, MUL_CLAMP, FMA_INL, ADDU, LSHL, ANDB, MADU24, FMAMK, MUL_SGPR, FMA_2DIFF, DOT4U8, DOT2I16, CVTUB, PKSUBI16, PERM, MADI24, SADU8, N_MODES };
 static const char* kNames[N_MODES] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32",
     "v_exp_f32", "v_log_f32", "v_rcp_f32", "v_fma_f32 -|a|", "v_fma_f32 literal", "v_fma_f32 sgpr", "mix 12 valu + exp + log",
-    "4 fma : 1 exp", "v_pk_fma_f32 op_sel", "v_max3_f32", "v_med3_f32", "v_add_f32 dpp row_shr", "v_cvt_f32_i32", "v_sub_f32", "v_max_f32", "v_min_f32", "v_fmac_f32", "v_mov_b32", "v_cndmask_b32", "v_fma_f32 clamp", "v_mul_f32 clamp(vop3)", "v_fma_f32 inline 1.0", "v_add_u32", "v_lshlrev_b32", "v_and_b32", "v_mad_u32_u24", "v_fmamk_f32", "v_mul_f32 sgpr", "v_fma_f32 3 distinct srcs" };
+    "4 fma : 1 exp", "v_pk_fma_f32 op_sel", "v_max3_f32", "v_med3_f32", "v_add_f32 dpp row_shr", "v_cvt_f32_i32", "v_sub_f32", "v_max_f32", "v_min_f32", "v_fmac_f32", "v_mov_b32", "v_cndmask_b32", "v_fma_f32 clamp", "v_mul_f32 clamp(vop3)", "v_fma_f32 inline 1.0", "v_add_u32", "v_lshlrev_b32", "v_and_b32", "v_mad_u32_u24", "v_fmamk_f32", "v_mul_f32 sgpr", "v_fma_f32 3 distinct srcs", "v_dot4_u32_u8", "v_dot2_i32_i16", "v_cvt_f32_ubyte1", "v_pk_sub_i16", "v_perm_b32", "v_mad_i32_i24", "v_sad_u8" };
 
 constexpr int kPerTrip = 128;
 
@@ -69,6 +69,13 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* stamps, float* sin
 #define I_MADU(i)  asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
 #define I_FMAMK(i) asm volatile("v_fmamk_f32 %0, %0, 0x3f8ccccd, %1" : "+v"(a[i]) : "v"(c));
 #define I_MULS(i)  asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[i]) : "s"(sarg));
+#define I_DOT4(i)  asm volatile("v_dot4_u32_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+#define I_DOT2(i)  asm volatile("v_dot2_i32_i16 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+#define I_CVTUB(i) asm volatile("v_cvt_f32_ubyte1 %0, %0" : "+v"(a[i]));
+#define I_PKSUB(i) asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+#define I_PERM(i)  asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+#define I_MADI(i)  asm volatile("v_mad_i32_i24 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+#define I_SAD(i)   asm volatile("v_sad_u8 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
 #define I_FMA3(i)  asm volatile("v_fma_f32 %0, %1, %2, %3" : "+v"(a[i]) : "v"(a[(i+1)&7]), "v"(m), "v"(c));
         if (MODE == FMA)   { REP16x8(I_FMA) }
         if (MODE == MUL)   { REP16x8(I_MUL) }
@@ -103,6 +110,13 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* stamps, float* sin
         if (MODE == FMAMK) { REP16x8(I_FMAMK) }
         if (MODE == MUL_SGPR) { REP16x8(I_MULS) }
         if (MODE == FMA_2DIFF) { REP16x8(I_FMA3) }
+        if (MODE == DOT4U8)  { REP16x8(I_DOT4) }
+        if (MODE == DOT2I16) { REP16x8(I_DOT2) }
+        if (MODE == CVTUB)   { REP16x8(I_CVTUB) }
+        if (MODE == PKSUBI16) { REP16x8(I_PKSUB) }
+        if (MODE == PERM)    { REP16x8(I_PERM) }
+        if (MODE == MADI24)  { REP16x8(I_MADI) }
+        if (MODE == SADU8)   { REP16x8(I_SAD) }
         if (MODE == MIX_TAP) {
             // the shape of one a-trous tap for a pixel pair: 8 x (12 plain + 1 exp + 1 log + 2 pk) = 128
 #pragma unroll
@@ -206,5 +220,12 @@ int main()
     run<LSHL>(d_st, d_sink);
     run<ANDB>(d_st, d_sink);
     run<MADU24>(d_st, d_sink);
+    run<DOT4U8>(d_st, d_sink);
+    run<DOT2I16>(d_st, d_sink);
+    run<CVTUB>(d_st, d_sink);
+    run<PKSUBI16>(d_st, d_sink);
+    run<PERM>(d_st, d_sink);
+    run<MADI24>(d_st, d_sink);
+    run<SADU8>(d_st, d_sink);
     return 0;
 }
