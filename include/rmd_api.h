@@ -203,6 +203,11 @@ int rmd_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, in
  * buffer geometry as f; f->nd supplies normals/depth). */
 int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
                     const float* in, float* out, int row0, int row1, void* stream);
+/* The same iteration on TWO row ranges, [row0,row1) and [row0b,row1b) behind it, in ONE launch (the two boundary bands of a
+ * strip's exchanged iteration: as two launches of one step each they cost twice the fixed part of a launch).  Same bits
+ * as two calls.  row0b >= row1b: no second range. */
+int rmd_svgf_atrous2(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
+                     const float* in, float* out, int row0, int row1, int row0b, int row1b, void* stream);
 /* Variant 7 synchronises its waves with counters in LDS; every wait is bounded, and a wait that runs out
  * is counted here instead of hanging the GPU (synchronises the device; 0 after any number of correct launches). */
 int rmd_debug_atrous_protocol_errors(unsigned int* count);

@@ -65,6 +65,9 @@ struct AtrousArgs {
     // bands of half the height (xe_lo of them at the left, the rest of the non-interior ones at the right)
     int n_int, xe_lo, band_h_xe, total_int, int_per_xcd, xe_per_xcd;
     int n_hi, band_h_hi, nblocks_hi;   // stream kernel: the first n_hi/2 and last n_hi - n_hi/2 strips are cut into bands of band_h_hi (< band_h) rows
+    // a SECOND row range in the same launch (stream kernel; the two boundary bands of a strip's exchanged iteration, which would
+    // otherwise be two launches of one step each): its own band plan, workgroups nblocks .. nblocks + b_nblocks - 1
+    int b_row0, b_row1, b_band_h, b_band_base, b_nblocks, b_n_hi, b_band_h_hi, b_nblocks_hi;
     int cus;       // CUs the launch may count on (rmd_svgf_params.atrous_cus or the whole device)
     int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
 };
@@ -766,24 +769,31 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(A
     // XCD-aware remap: workgroups pid, pid+8, ... share an XCD (round-robin dispatch), give each
     // XCD one contiguous run of logical work so halo columns / variance rows are shared in its L2.
     const int pid = blockIdx.x;
-    const int L = (pid & (kXcds - 1)) * a.per_xcd + (pid >> 3);
-    if (L >= a.nblocks) return;
+    int L = (pid & (kXcds - 1)) * a.per_xcd + (pid >> 3);
+    if (L >= a.nblocks + a.b_nblocks) return;
+    // the launch's second row range, if any, follows the first in the workgroup order (scalar selects: L is wave-uniform)
+    const bool second = L >= a.nblocks;
+    if (second) L -= a.nblocks;
+    const int p_row0 = second ? a.b_row0 : a.row0, p_row1 = second ? a.b_row1 : a.row1;
+    const int p_band_h = second ? a.b_band_h : a.band_h, p_band_base = second ? a.b_band_base : a.band_base;
+    const int p_n_hi = second ? a.b_n_hi : a.n_hi, p_band_h_hi = second ? a.b_band_h_hi : a.band_h_hi;
+    const int p_nblocks_hi = second ? a.b_nblocks_hi : a.nblocks_hi;
     // Two groups of strips: n_hi strips (the outermost ones: their frame-edge body is the slower one) are cut into
     // one band more than the others, so that the workgroup count lands on the resident slots (plan_stream).
     int strip, band, bh;
     const int r = L % S;
-    if (L < a.nblocks_hi) {
-        const int t = L / S, e = t % a.n_hi;
-        strip = e < a.n_hi / 2 ? e : a.nstrips - (a.n_hi - e); band = t / a.n_hi; bh = a.band_h_hi;
+    if (L < p_nblocks_hi) {
+        const int t = L / S, e = t % p_n_hi;
+        strip = e < p_n_hi / 2 ? e : a.nstrips - (p_n_hi - e); band = t / p_n_hi; bh = p_band_h_hi;
     } else {
-        const int t = (L - a.nblocks_hi) / S, n_lo = a.nstrips - a.n_hi;
-        strip = a.n_hi / 2 + t % n_lo; band = t / n_lo; bh = a.band_h;
+        const int t = (L - p_nblocks_hi) / S, n_lo = a.nstrips - p_n_hi;
+        strip = p_n_hi / 2 + t % n_lo; band = t / n_lo; bh = p_band_h;
     }
     const int x0 = strip * C::CW;
     // bands start at band_base + k*bh; band_base is row0 rounded down to a multiple of 2S, which is
     // all the (A,B) pairing needs (global lattice index floor(y/S) even at the top of a band)
-    const int yb = a.band_base + band * bh;
-    const int lo = max(yb, a.row0), hi = min(yb + bh, a.row1);
+    const int yb = p_band_base + band * bh;
+    const int lo = max(yb, p_row0), hi = min(yb + bh, p_row1);
     const int ybase = yb + r;
     const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
     const int jhi = hi > ybase ? (hi - ybase + S - 1) / S : 0;      // exclusive
@@ -912,7 +922,17 @@ static int launch_planned(const AtrousArgs& a, hipStream_t stream)
 template <int S, int NP>
 static int launch_stream(AtrousArgs a, hipStream_t stream)
 {
+    const int b0 = a.b_row0, b1 = a.b_row1;
+    a.b_nblocks = 0;
+    if (b1 > b0) {              // second range: planned on its own, appended to the first in the workgroup order
+        AtrousArgs b = a;
+        b.row0 = b0; b.row1 = b1;
+        plan_stream<S, NP>(b);
+        a.b_band_h = b.band_h; a.b_band_base = b.band_base; a.b_nblocks = b.nblocks;
+        a.b_n_hi = b.n_hi; a.b_band_h_hi = b.band_h_hi; a.b_nblocks_hi = b.nblocks_hi;
+    }
     plan_stream<S, NP>(a);
+    a.per_xcd = (a.nblocks + a.b_nblocks + kXcds - 1) / kXcds;
     return launch_planned<S, NP>(a, stream);
 }
 
@@ -964,6 +984,7 @@ extern "C" int rmd_debug_atrous_plan(int width, int height, int row0, int row1, 
     a.g = Geom{ width, height, 0, height };
     a.row0 = row0; a.row1 = row1; a.step = 1 << iteration; a.cus = cus;
     a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
+    a.b_row0 = a.b_row1 = a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
     switch (iteration) {
         case 0: plan_stream<1, 2>(a); break;
         case 1: plan_stream<2, 2>(a); break;
@@ -990,6 +1011,12 @@ extern "C" int rmd_debug_atrous_protocol_errors(unsigned int* count)
 extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
                                const float* in, float* out, int row0, int row1, void* stream)
 {
+    return rmd_svgf_atrous2(f, p, iteration, in, out, row0, row1, 0, 0, stream);
+}
+
+extern "C" int rmd_svgf_atrous2(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
+                                const float* in, float* out, int row0, int row1, int row0b, int row1b, void* stream)
+{
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_atrous: params is NULL");
     if (!in || !out || !f->nd) return fail(RMD_E_NULL, "rmd_svgf_atrous: in/out/nd plane is NULL");
@@ -1000,6 +1027,16 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     if (row0 < 0 || row1 > f->height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_svgf_atrous: rows [%d,%d) invalid", row0, row1);
     const int s = 1 << iteration;
     if (int e = check_rows_in_buffer(f, row0 - 2 * s, row1 + 2 * s, "rmd_svgf_atrous")) return e;
+    const bool two = row1b > row0b;
+    // only the default row-streaming kernel takes two row ranges in one launch; every other form runs them one after the other
+    if (two && !((p->atrous_variant == 0 || p->atrous_variant == 3) && iteration <= 4)) {
+        if (int e = rmd_svgf_atrous(f, p, iteration, in, out, row0, row1, stream)) return e;
+        return rmd_svgf_atrous(f, p, iteration, in, out, row0b, row1b, stream);
+    }
+    if (two) {
+        if (row0b < row1 || row1b > f->height) return fail(RMD_E_ROWS, "rmd_svgf_atrous2: second range [%d,%d) must lie behind the first [%d,%d)", row0b, row1b, row0, row1);
+        if (int e = check_rows_in_buffer(f, row0b - 2 * s, row1b + 2 * s, "rmd_svgf_atrous2")) return e;
+    }
     if (!aligned_to(in, 16) || !aligned_to(out, 16) || !aligned_to(f->nd, 16))
         return fail(RMD_E_ALIGN, "rmd_svgf_atrous: float4 planes must be 16-byte aligned");
 
@@ -1011,7 +1048,9 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     a.band_h = a.band_base = a.nstrips = a.nblocks = a.per_xcd = 0;
     a.n_int = a.xe_lo = a.band_h_xe = a.total_int = a.int_per_xcd = a.xe_per_xcd = 0;
     a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
-    a.nt_out = (double)(row1 - row0) * f->width * 48.0 > 256.0e6 ? 1 : 0;
+    a.b_row0 = two ? row0b : 0; a.b_row1 = two ? row1b : 0;
+    a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
+    a.nt_out = (double)(row1 - row0 + (two ? row1b - row0b : 0)) * f->width * 48.0 > 256.0e6 ? 1 : 0;
     if (p->atrous_cus < 0) return fail(RMD_E_PARAM, "rmd_svgf_atrous: atrous_cus %d is negative", p->atrous_cus);
     a.cus = p->atrous_cus > 0 && p->atrous_cus < device_cus() ? p->atrous_cus : device_cus();
 

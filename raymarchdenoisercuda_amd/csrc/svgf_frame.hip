@@ -225,8 +225,11 @@ int rmd_svgf_frame_atrous_part(const rmd_svgf_frame_desc* f, const rmd_svgf_para
         } else if (part == RMD_ATROUS_INTERIOR && at) {
             if (hi > lo) { ranges[nr][0] = lo; ranges[nr][1] = hi; ++nr; }
         }
-        for (int q = 0; q < nr; ++q)
-            if (int e = rmd_svgf_atrous(f, p, i, in, out, ranges[q][0], ranges[q][1], stream)) return e;
+        if (nr == 2) {          // the two boundary bands of the exchanged iteration: one launch
+            if (int e = rmd_svgf_atrous2(f, p, i, in, out, ranges[0][0], ranges[0][1], ranges[1][0], ranges[1][1], stream)) return e;
+        } else if (nr == 1) {
+            if (int e = rmd_svgf_atrous(f, p, i, in, out, ranges[0][0], ranges[0][1], stream)) return e;
+        }
         if (nr == 0) continue;
         if (at && part == RMD_ATROUS_HEAD && hi > lo) continue;        // (iteration mid is complete only after its interior part)
         if (i == n - 1 && i == p->hist_iteration && f->hist_color_out != out) {

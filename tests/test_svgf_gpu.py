@@ -176,6 +176,38 @@ def test_atrous_zero_normals_cornell(rmd, orc, cuda):
             src = ref
 
 
+def test_two_row_ranges_in_one_launch_equal_two_launches(rmd, cuda):
+    """rmd_svgf_atrous2: the two boundary bands of a strip's exchanged iteration in ONE launch (each range its own band plan,
+    appended in the workgroup order) give the bits of the full-frame launch on those rows and touch nothing else."""
+    import ctypes as C
+    width, height = 300, 200
+    c, nd, m = rmd.svgf.synth_gbuffer(width, height, 2)
+    c[..., 3] = torch.rand((height, width), device="cuda") * 0.2
+    d = rmd.svgf.frame_desc(width, height, nd=nd)
+    p = rmd.default_params()
+    for it in range(5):
+        full = torch.empty_like(c)
+        rmd.svgf.atrous(d, p, it, c, full, 0, height)
+        for (a0, a1, b0, b1) in ((40, 72, 140, 172), (0, 32, 168, 200), (17, 18, 19, 87), (64, 96, 96, 128)):
+            got = torch.full_like(c, -7.0)
+            rmd.check(rmd.lib.rmd_svgf_atrous2(C.byref(d), C.byref(p), it, c.data_ptr(), got.data_ptr(), a0, a1, b0, b1, None))
+            torch.cuda.synchronize()
+            assert torch.equal(got[a0:a1], full[a0:a1]) and torch.equal(got[b0:b1], full[b0:b1]), f"iteration {it} ranges {(a0, a1, b0, b1)}"
+            rest = torch.ones(height, dtype=torch.bool, device="cuda")
+            rest[a0:a1] = False
+            rest[b0:b1] = False
+            assert (got[rest] == -7.0).all(), f"iteration {it}: rows outside the two ranges were written"
+        assert rmd.lib.rmd_svgf_atrous2(C.byref(d), C.byref(p), it, c.data_ptr(), full.data_ptr(), 40, 72, 60, 90, None) == -5   # overlapping / unordered
+    p.atrous_variant = 1                                   # the direct kernel: two launches behind the same entry point
+    got = torch.full_like(c, -7.0)
+    rmd.check(rmd.lib.rmd_svgf_atrous2(C.byref(d), C.byref(p), 2, c.data_ptr(), got.data_ptr(), 8, 24, 100, 150, None))
+    p.atrous_variant = 0
+    full = torch.empty_like(c)
+    rmd.svgf.atrous(d, p, 2, c, full, 0, height)
+    torch.cuda.synchronize()
+    assert torch.equal(got[8:24], full[8:24]) and torch.equal(got[100:150], full[100:150])
+
+
 def test_atrous_row_ranges_match_full_frame(rmd, cuda):
     """Any output row range gives the bits of the whole-frame run (basis of row-strip sharding)."""
     width, height = 300, 200
