@@ -24,6 +24,7 @@
 // weighted_filter_kernel, one thread per pixel, a wave owns 64 consecutive x (coalesced 4-byte loads, neighbours
 // re-served by L1/L2).  8 B/px/level algorithmic like the box filter; this is not the graded kernel.
 #include <cmath>
+#include <type_traits>
 #include "common.h"
 
 namespace rmd {
@@ -115,6 +116,119 @@ __global__ __launch_bounds__(256) void weighted_filter_kernel(WeightedArgs a)
     }
     // the centre tap has weight k(0,0) > 0, so sw > 0
     a.out[i] = make_uchar4((unsigned char)(sr / sw), (unsigned char)(sg / sw), (unsigned char)(sb / sw), 0);
+}
+
+// ---- CROSS / WAVELET at spacing 1, 5x5 window: tile in LDS, two pixels per thread -------------------------------------------
+// weighted_filter_kernel is VALU-bound (~36 instructions + v_exp per tap, one pixel per thread, every tap converted from
+// bytes again).  Here a thread owns TWO pixels of a 64 x 8 tile, A in row y and B in row y + 4 of the same column, and every
+// tap (dx, dy) is weighed for both at once with packed f32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma): lane 0 of the packed
+// registers is A's window, lane 1 is B's.  The planes are converted to float once per staged pixel, and the LDS image is laid
+// out FOR the packed operands: entry [r][c] of a plane holds the values of region rows r and r + 4 side by side
+// ({rA, rB, gA, gB} and {bA, bB, |t_A|^2, |t_B|^2}), so that one ds_read_b128 lands both pixels' tap in an aligned register
+// pair (rows 4..7 of the 12-row region are stored twice: as the B half of entry r - 4 and the A half of entry r).
+// Squared distances are formed as |k|^2 + |t|^2 - 2 k.t: all terms are integers below 2^24, hence exactly the oracle's
+// value whatever the grouping.  Exponent and sums use the oracle's fused multiply-adds in its order (dx outer, dy inner;
+// colour, albedo, normal), so the only difference to the oracle stays v_exp_f32 against expf, as in weighted_filter_kernel.
+// Out-of-frame taps get weight 0, which adds exactly nothing.  LDS 17 KB per plane (52 KB with all three: 3 workgroups
+// per CU, the VGPR budget's 3 waves per SIMD); the next tap's reads are issued before the current tap is weighed.
+typedef float wf2 __attribute__((ext_vector_type(2)));
+
+template <bool HAS_A, bool HAS_N, bool WAVELET>
+__global__ __launch_bounds__(256, 3) void weighted_tile_kernel(WeightedArgs a)
+{
+    constexpr int TW = 64, R = 2, RW = TW + 2 * R, NR = 8, NP = 1 + (HAS_A ? 1 : 0) + (HAS_N ? 1 : 0);
+    __shared__ float4 prg[NP][NR][RW], pbt[NP][NR][RW];
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * 8;
+    const uchar4* const planes[3] = { a.in, HAS_A ? a.albedo : a.normal, a.normal };          // in the oracle's order of terms
+    const float inv2s[3] = { a.inv2s_color, HAS_A ? a.inv2s_albedo : a.inv2s_normal, a.inv2s_normal };
+    auto put = [&](const int p, const int r, const int c, const uchar4 u, const uchar4 v) {      // entry r: region rows r (A half) and r + 4 (B half)
+        const wf2 rp = { (float)u.x, (float)v.x }, gp = { (float)u.y, (float)v.y }, bp = { (float)u.z, (float)v.z };
+        const wf2 tt = __builtin_elementwise_fma(bp, bp, __builtin_elementwise_fma(gp, gp, rp * rp));
+        prg[p][r][c] = make_float4(rp.x, rp.y, gp.x, gp.y);
+        pbt[p][r][c] = make_float4(bp.x, bp.y, tt.x, tt.y);
+    };
+    auto row_of = [&](const int r) { return (size_t)min(max(y0 - R + r, 0), a.H - 1) * a.W; };
+    {   // region columns 0..63: a thread reads region rows wv, wv + 4, wv + 8 of its column and writes entries wv and wv + 4
+        const int gx = min(max(x0 - R + lx, 0), a.W - 1);
+        const size_t i0 = row_of(wv) + gx, i1 = row_of(wv + 4) + gx, i2 = row_of(wv + 8) + gx;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const uchar4 u0 = planes[p][i0], u1 = planes[p][i1], u2 = planes[p][i2];
+            put(p, wv, lx, u0, u1);
+            put(p, wv + 4, lx, u1, u2);
+        }
+    }
+    if (threadIdx.x < 4 * NR) {   // region columns 64..67, 8 entries each: half a wave
+        const int r = threadIdx.x >> 2, c = TW + (threadIdx.x & 3);
+        const int gx = min(max(x0 - R + c, 0), a.W - 1);
+        const size_t iA = row_of(r) + gx, iB = row_of(r + 4) + gx;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) put(p, r, c, planes[p][iA], planes[p][iB]);
+    }
+    __syncthreads();
+    const int x = x0 + lx, yA = y0 + wv, yB = yA + 4;
+    if (x >= a.W || yA >= a.H) return;
+    const bool inside = x0 - R >= 0 && x0 + TW + R <= a.W && y0 - R >= 0 && y0 + 8 + R <= a.H;     // no tap of the tile leaves the frame
+    const int cx = lx + R;
+    struct Tap { float4 rg[NP], bt[NP]; };
+    auto fetch = [&](const int dx, const int dyi) {              // window offset (dx, dyi - 2) of both pixels: entry row wv + dyi
+        Tap t;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { t.rg[p] = prg[p][wv + dyi][cx + dx]; t.bt[p] = pbt[p][wv + dyi][cx + dx]; }
+        return t;
+    };
+    const Tap ctr = fetch(0, 2);
+    wf2 kr[NP], kg[NP], kb[NP], kk[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { kr[p] = wf2{ ctr.rg[p].x, ctr.rg[p].y }; kg[p] = wf2{ ctr.rg[p].z, ctr.rg[p].w }; kb[p] = wf2{ ctr.bt[p].x, ctr.bt[p].y }; kk[p] = wf2{ ctr.bt[p].z, ctr.bt[p].w }; }
+    wf2 sr = { 0, 0 }, sg = sr, sb = sr, sw = sr;
+    auto window = [&](auto inside_c) {
+        constexpr bool interior = decltype(inside_c)::value;
+        constexpr float spline[3] = { 0.375f, 0.25f, 0.0625f };
+        Tap nxt = fetch(-R, 0);
+#pragma unroll
+        for (int t = 0; t < 25; ++t) {
+            const int dx = t / 5 - R, dyi = t % 5, dy = dyi - R;
+            const Tap cur = nxt;
+            if (t + 1 < 25) nxt = fetch((t + 1) / 5 - R, (t + 1) % 5);
+            __builtin_amdgcn_sched_barrier(0);               // the next tap's reads stay ahead of this tap's arithmetic
+            wf2 e = { 0, 0 };
+            if (!WAVELET) { const float e0 = (float)(dx * dx + dy * dy) * a.inv2s_space; e = wf2{ e0, e0 }; }
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const wf2 tr = { cur.rg[p].x, cur.rg[p].y }, tg = { cur.rg[p].z, cur.rg[p].w }, tb = { cur.bt[p].x, cur.bt[p].y }, tt = { cur.bt[p].z, cur.bt[p].w };
+                const wf2 dot = __builtin_elementwise_fma(kb[p], tb, __builtin_elementwise_fma(kg[p], tg, kr[p] * tr));
+                const wf2 d2 = __builtin_elementwise_fma(dot, wf2{ -2.0f, -2.0f }, kk[p] + tt);
+                e = __builtin_elementwise_fma(d2, wf2{ inv2s[p], inv2s[p] }, e);
+            }
+            const wf2 m = e * wf2{ -1.442695041f, -1.442695041f };            // __expf(-e) = v_exp_f32(-e * log2(e)): the same product
+            wf2 w = { __builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y) };
+            if (WAVELET) { const float k = spline[dx < 0 ? -dx : dx] * spline[dy < 0 ? -dy : dy]; w = wf2{ k, k } * w; }
+            if (!interior) {
+                const bool colv = x + dx >= 0 && x + dx < a.W;
+                if (!(colv && yA + dy >= 0 && yA + dy < a.H)) w.x = 0.0f;
+                if (!(colv && yB + dy >= 0 && yB + dy < a.H)) w.y = 0.0f;
+            }
+            sr = __builtin_elementwise_fma(w, wf2{ cur.rg[0].x, cur.rg[0].y }, sr);
+            sg = __builtin_elementwise_fma(w, wf2{ cur.rg[0].z, cur.rg[0].w }, sg);
+            sb = __builtin_elementwise_fma(w, wf2{ cur.bt[0].x, cur.bt[0].y }, sb);
+            sw += w;
+        }
+    };
+    if (inside) window(std::true_type{}); else window(std::false_type{});
+    // the centre tap has weight k(0,0) > 0, so sw > 0
+    a.out[(size_t)yA * a.W + x] = make_uchar4((unsigned char)(sr.x / sw.x), (unsigned char)(sg.x / sw.x), (unsigned char)(sb.x / sw.x), 0);
+    if (yB < a.H)
+        a.out[(size_t)yB * a.W + x] = make_uchar4((unsigned char)(sr.y / sw.y), (unsigned char)(sg.y / sw.y), (unsigned char)(sb.y / sw.y), 0);
+}
+
+template <bool HAS_A, bool HAS_N>
+static void launch_weighted_tile(const WeightedArgs& a, hipStream_t stream)
+{
+    const dim3 grid((a.W + 63) / 64, (a.H + 7) / 8);
+    if (a.mode == RMD_FILTER_WAVELET) hipLaunchKernelGGL(HIP_KERNEL_NAME(weighted_tile_kernel<HAS_A, HAS_N, true>), grid, dim3(256), 0, stream, a);
+    else                              hipLaunchKernelGGL(HIP_KERNEL_NAME(weighted_tile_kernel<HAS_A, HAS_N, false>), grid, dim3(256), 0, stream, a);
 }
 
 // ---- GAUSSIAN, radius R, step 1: separable.  out = sum_dy g(dy) [sum_dx g(dx) c(x+dx, y+dy)] / (hw(x) vw(y)) over the taps
@@ -262,6 +376,14 @@ int run_weighted_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStr
                 default: launch_gaussian<0>(ga, stream); break;
             }
             RMD_LAUNCH_CHECK("gaussian_separable_kernel");
+            continue;
+        }
+        if (a.radius == 2 && a.step == 1 && tuning_env("RMD_WEIGHTED_TILE", 1)) {            // CROSS radius 2, WAVELET at spacing 1
+            if (a.albedo && a.normal) launch_weighted_tile<true, true>(a, stream);
+            else if (a.albedo)        launch_weighted_tile<true, false>(a, stream);
+            else if (a.normal)        launch_weighted_tile<false, true>(a, stream);
+            else                      launch_weighted_tile<false, false>(a, stream);
+            RMD_LAUNCH_CHECK("weighted_tile_kernel");
             continue;
         }
         dim3 grid((W + 63) / 64, (H + 3) / 4);

@@ -87,19 +87,44 @@ def test_cornell_against_oracle(rmd, orc, cuda, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (37, 61), (130, 257)])
+@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (9, 200), (37, 61), (130, 257)])
 def test_ragged_shapes_and_missing_planes(rmd, orc, cuda, shape):
+    # (9, 200): the last 64 x 8 tile of the CROSS / WAVELET kernel holds one row and 8 columns; (1, 1), (3, 7): windows larger than the frame
     rng = np.random.default_rng(9)
     img = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
     alb = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
+    nrm = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
     for mode in ("GAUSSIAN", "CROSS", "WAVELET"):
         p = make_params(rmd, getattr(rmd.FilterParams, mode), depth=2)
         assert_close_u8(gpu_run(rmd, img, p, None, alb), orc.weighted_filter(img, p, None, alb), exact=mode == "GAUSSIAN")   # no normal plane
+        assert_close_u8(gpu_run(rmd, img, p, nrm, None), orc.weighted_filter(img, p, nrm, None), exact=mode == "GAUSSIAN")   # no albedo plane
+        assert_close_u8(gpu_run(rmd, img, p, nrm, alb), orc.weighted_filter(img, p, nrm, alb), exact=mode == "GAUSSIAN")
         p0 = make_params(rmd, getattr(rmd.FilterParams, mode), sigmaAlbedo=0.0, sigmaNormal=0.0)
         assert_close_u8(gpu_run(rmd, img, p0), orc.weighted_filter(img, p0), exact=mode == "GAUSSIAN")
     for radius in (0, 1, 3, 7, 12):          # GAUSSIAN: every radius the separable kernel takes (1..4 unrolled, the rest at run time)
         pg = make_params(rmd, rmd.FilterParams.GAUSSIAN, radius=radius, sigmaSpace=0.8 + radius)
         assert_close_u8(gpu_run(rmd, img, pg), orc.weighted_filter(img, pg), exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.experiments
+@pytest.mark.parametrize("mode", ["CROSS", "WAVELET"])
+def test_tile_kernel_equals_gather_kernel_at_4k(rmd, cuda, mode, monkeypatch):
+    """Size-independent property at BASELINE's frame size: the LDS-tile kernel (two pixels per thread, packed arithmetic,
+    distances as |k|^2 + |t|^2 - 2 k.t) and the one-pixel-per-thread gather kernel state the same fp32 operations in the same
+    order, so they agree byte for byte -- whatever v_exp_f32 returns.  (The gather kernel is selected by RMD_WEIGHTED_TILE=0,
+    which only the experiments build reads.)"""
+    rng = np.random.default_rng(21)
+    shape = (2160, 3840, 4)
+    img = (rng.integers(0, 256, shape, dtype=np.uint8) >> 2) + 96           # mid-range values: weights that are neither 0 nor 1
+    nrm = (rng.integers(0, 256, shape, dtype=np.uint8) >> 3) + 100
+    alb = (rng.integers(0, 256, shape, dtype=np.uint8) >> 3) + 100
+    p = make_params(rmd, getattr(rmd.FilterParams, mode), depth=1)
+    tile = gpu_run(rmd, img, p, nrm, alb)
+    monkeypatch.setenv("RMD_WEIGHTED_TILE", "0")
+    gather = gpu_run(rmd, img, p, nrm, alb)
+    assert len(np.unique(tile[..., :3])) > 32                              # the filter did something other than saturate
+    assert (tile == gather).all(), f"{(tile != gather).mean():.2e} of the bytes differ"
 
 
 @pytest.mark.gpu
