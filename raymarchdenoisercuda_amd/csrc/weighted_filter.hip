@@ -133,49 +133,64 @@ __global__ __launch_bounds__(256) void weighted_filter_kernel(WeightedArgs a)
 // per CU, the VGPR budget's 3 waves per SIMD); the next tap's reads are issued before the current tap is weighed.
 typedef float wf2 __attribute__((ext_vector_type(2)));
 
-template <bool HAS_A, bool HAS_N, bool WAVELET>
-__global__ __launch_bounds__(256, 3) void weighted_tile_kernel(WeightedArgs a)
+// Dilated WAVELET levels (spacing S = 2, 4, 8) are the same filter on the S row lattices y mod S: a workgroup takes 2 D
+// consecutive rows of ONE lattice (pairs j and j + D, D = 4), the region is those rows + 2 lattice rows either side and the
+// tile's 64 columns + 2 S either side, taps at column offsets dx S.  Their regions (55 .. 74 KB) leave a CU two workgroups
+// instead of three: 183-188 us per 4K level against 152 at S = 1 and 212 for the gather kernel.  At S = 16 the region is as
+// wide again as the tile (98 KB, one workgroup per CU; D = 8 with 512 threads and 147 KB measured 270 us): that level and
+// the ones above stay on the gather kernel.
+template <bool HAS_A, bool HAS_N, bool WAVELET, int S, int D>
+__global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel(WeightedArgs a)
 {
-    constexpr int TW = 64, R = 2, RW = TW + 2 * R, NR = 8, NP = 1 + (HAS_A ? 1 : 0) + (HAS_N ? 1 : 0);
-    __shared__ float4 prg[NP][NR][RW], pbt[NP][NR][RW];
+    constexpr int TW = 64, R = 2, RW = TW + 2 * R * S, NR = D + 2 * R, NP = 1 + (HAS_A ? 1 : 0) + (HAS_N ? 1 : 0);
+    constexpr int FULL = RW / 64, REM = RW - 64 * FULL;                 // whole 64-column chunks of the region, and the rest (a power of two)
+    extern __shared__ __attribute__((aligned(16))) float4 weighted_lds[];
+    float4* const prg = weighted_lds;                                    // [NP][NR][RW]  { rA, rB, gA, gB }
+    float4* const pbt = weighted_lds + NP * NR * RW;                     // [NP][NR][RW]  { bA, bB, |t_A|^2, |t_B|^2 }
+    auto at = [](const int p, const int r, const int c) { return (p * NR + r) * RW + c; };
     const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * 8;
+    const int group = blockIdx.y / S, lattice = blockIdx.y - group * S;
+    const int x0 = blockIdx.x * TW, y0 = group * (2 * D * S) + lattice;  // the tile's rows: y0 + j S, j = 0 .. 2 D - 1
     const uchar4* const planes[3] = { a.in, HAS_A ? a.albedo : a.normal, a.normal };          // in the oracle's order of terms
     const float inv2s[3] = { a.inv2s_color, HAS_A ? a.inv2s_albedo : a.inv2s_normal, a.inv2s_normal };
-    auto put = [&](const int p, const int r, const int c, const uchar4 u, const uchar4 v) {      // entry r: region rows r (A half) and r + 4 (B half)
+    auto put = [&](const int p, const int r, const int c, const uchar4 u, const uchar4 v) {      // entry r: region rows r (A half) and r + D (B half)
         const wf2 rp = { (float)u.x, (float)v.x }, gp = { (float)u.y, (float)v.y }, bp = { (float)u.z, (float)v.z };
         const wf2 tt = __builtin_elementwise_fma(bp, bp, __builtin_elementwise_fma(gp, gp, rp * rp));
-        prg[p][r][c] = make_float4(rp.x, rp.y, gp.x, gp.y);
-        pbt[p][r][c] = make_float4(bp.x, bp.y, tt.x, tt.y);
+        prg[at(p, r, c)] = make_float4(rp.x, rp.y, gp.x, gp.y);
+        pbt[at(p, r, c)] = make_float4(bp.x, bp.y, tt.x, tt.y);
     };
-    auto row_of = [&](const int r) { return (size_t)min(max(y0 - R + r, 0), a.H - 1) * a.W; };
-    {   // region columns 0..63: a thread reads region rows wv, wv + 4, wv + 8 of its column and writes entries wv and wv + 4
-        const int gx = min(max(x0 - R + lx, 0), a.W - 1);
-        const size_t i0 = row_of(wv) + gx, i1 = row_of(wv + 4) + gx, i2 = row_of(wv + 8) + gx;
+    auto row_of = [&](const int r) { return (size_t)min(max(y0 + (r - R) * S, 0), a.H - 1) * a.W; };        // region row r
+    auto col_of = [&](const int c) { return min(max(x0 - R * S + c, 0), a.W - 1); };                        // region column c
+    {   // the whole chunks: a thread reads region rows wv, wv + D (and wv + 2 D) of its column and writes entries wv (and wv + D)
+        const size_t r0 = row_of(wv), r1 = row_of(wv + D), r2 = row_of(wv + 2 * D);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const uchar4 u0 = planes[p][i0], u1 = planes[p][i1], u2 = planes[p][i2];
-            put(p, wv, lx, u0, u1);
-            put(p, wv + 4, lx, u1, u2);
+        for (int i = 0; i < FULL; ++i) {
+            const int c = lx + 64 * i, gx = col_of(c);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uchar4 u0 = planes[p][r0 + gx], u1 = planes[p][r1 + gx];
+                put(p, wv, c, u0, u1);
+                if (wv < 2 * R) put(p, wv + D, c, u1, planes[p][r2 + gx]);
+            }
         }
     }
-    if (threadIdx.x < 4 * NR) {   // region columns 64..67, 8 entries each: half a wave
-        const int r = threadIdx.x >> 2, c = TW + (threadIdx.x & 3);
-        const int gx = min(max(x0 - R + c, 0), a.W - 1);
-        const size_t iA = row_of(r) + gx, iB = row_of(r + 4) + gx;
+    if (REM > 0)
+        for (int q = threadIdx.x; q < REM * NR; q += 64 * D) {           // the remaining columns, every entry: as few waves as hold them
+            const int r = q / (REM > 0 ? REM : 1), c = 64 * FULL + (q - r * REM), gx = col_of(c);
+            const size_t rA = row_of(r), rB = row_of(r + D);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) put(p, r, c, planes[p][iA], planes[p][iB]);
-    }
+            for (int p = 0; p < NP; ++p) put(p, r, c, planes[p][rA + gx], planes[p][rB + gx]);
+        }
     __syncthreads();
-    const int x = x0 + lx, yA = y0 + wv, yB = yA + 4;
+    const int x = x0 + lx, yA = y0 + wv * S, yB = yA + D * S;
     if (x >= a.W || yA >= a.H) return;
-    const bool inside = x0 - R >= 0 && x0 + TW + R <= a.W && y0 - R >= 0 && y0 + 8 + R <= a.H;     // no tap of the tile leaves the frame
-    const int cx = lx + R;
+    const bool inside = x0 - R * S >= 0 && x0 + TW + R * S <= a.W && y0 - R * S >= 0 && y0 + (2 * D - 1 + R) * S < a.H;     // no tap of the tile leaves the frame
+    const int cx = lx + R * S;
     struct Tap { float4 rg[NP], bt[NP]; };
-    auto fetch = [&](const int dx, const int dyi) {              // window offset (dx, dyi - 2) of both pixels: entry row wv + dyi
+    auto fetch = [&](const int dx, const int dyi) {              // window offset (dx S, (dyi - 2) S) of both pixels: entry row wv + dyi
         Tap t;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) { t.rg[p] = prg[p][wv + dyi][cx + dx]; t.bt[p] = pbt[p][wv + dyi][cx + dx]; }
+        for (int p = 0; p < NP; ++p) { t.rg[p] = prg[at(p, wv + dyi, cx + dx * S)]; t.bt[p] = pbt[at(p, wv + dyi, cx + dx * S)]; }
         return t;
     };
     const Tap ctr = fetch(0, 2);
@@ -192,7 +207,7 @@ __global__ __launch_bounds__(256, 3) void weighted_tile_kernel(WeightedArgs a)
             const int dx = t / 5 - R, dyi = t % 5, dy = dyi - R;
             const Tap cur = nxt;
             if (t + 1 < 25) nxt = fetch((t + 1) / 5 - R, (t + 1) % 5);
-            __builtin_amdgcn_sched_barrier(0);               // the next tap's reads stay ahead of this tap's arithmetic
+            __builtin_amdgcn_sched_barrier(0);               // the next tap's reads stay ahead of this tap's arithmetic (deeper: no gain)
             wf2 e = { 0, 0 };
             if (!WAVELET) { const float e0 = (float)(dx * dx + dy * dy) * a.inv2s_space; e = wf2{ e0, e0 }; }
 #pragma unroll
@@ -206,9 +221,9 @@ __global__ __launch_bounds__(256, 3) void weighted_tile_kernel(WeightedArgs a)
             wf2 w = { __builtin_amdgcn_exp2f(m.x), __builtin_amdgcn_exp2f(m.y) };
             if (WAVELET) { const float k = spline[dx < 0 ? -dx : dx] * spline[dy < 0 ? -dy : dy]; w = wf2{ k, k } * w; }
             if (!interior) {
-                const bool colv = x + dx >= 0 && x + dx < a.W;
-                if (!(colv && yA + dy >= 0 && yA + dy < a.H)) w.x = 0.0f;
-                if (!(colv && yB + dy >= 0 && yB + dy < a.H)) w.y = 0.0f;
+                const bool colv = x + dx * S >= 0 && x + dx * S < a.W;
+                if (!(colv && yA + dy * S >= 0 && yA + dy * S < a.H)) w.x = 0.0f;
+                if (!(colv && yB + dy * S >= 0 && yB + dy * S < a.H)) w.y = 0.0f;
             }
             sr = __builtin_elementwise_fma(w, wf2{ cur.rg[0].x, cur.rg[0].y }, sr);
             sg = __builtin_elementwise_fma(w, wf2{ cur.rg[0].z, cur.rg[0].w }, sg);
@@ -223,12 +238,33 @@ __global__ __launch_bounds__(256, 3) void weighted_tile_kernel(WeightedArgs a)
         a.out[(size_t)yB * a.W + x] = make_uchar4((unsigned char)(sr.y / sw.y), (unsigned char)(sg.y / sw.y), (unsigned char)(sb.y / sw.y), 0);
 }
 
-template <bool HAS_A, bool HAS_N>
-static void launch_weighted_tile(const WeightedArgs& a, hipStream_t stream)
+constexpr int kTileMaxStep = 8;
+
+template <bool HAS_A, bool HAS_N, bool WAVELET, int S, int D>
+static int launch_weighted_tile_at(const WeightedArgs& a, hipStream_t stream)
 {
-    const dim3 grid((a.W + 63) / 64, (a.H + 7) / 8);
-    if (a.mode == RMD_FILTER_WAVELET) hipLaunchKernelGGL(HIP_KERNEL_NAME(weighted_tile_kernel<HAS_A, HAS_N, true>), grid, dim3(256), 0, stream, a);
-    else                              hipLaunchKernelGGL(HIP_KERNEL_NAME(weighted_tile_kernel<HAS_A, HAS_N, false>), grid, dim3(256), 0, stream, a);
+    constexpr int NP = 1 + (HAS_A ? 1 : 0) + (HAS_N ? 1 : 0), RW = 64 + 4 * S, NR = D + 4;
+    constexpr int lds_bytes = 2 * (int)sizeof(float4) * NP * NR * RW;
+    static_assert(lds_bytes <= 160 * 1024, "region larger than a CU's LDS");
+    const auto kernel = &weighted_tile_kernel<HAS_A, HAS_N, WAVELET, S, D>;
+    if (first_use_on_device(reinterpret_cast<const void*>(kernel)))
+        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    const dim3 grid((a.W + 63) / 64, ((a.H + 2 * D * S - 1) / (2 * D * S)) * S);
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * D), lds_bytes, stream, a);
+    RMD_LAUNCH_CHECK("weighted_tile_kernel");
+    return RMD_OK;
+}
+
+template <bool HAS_A, bool HAS_N>
+static int launch_weighted_tile(const WeightedArgs& a, hipStream_t stream)
+{
+    if (a.mode != RMD_FILTER_WAVELET) return launch_weighted_tile_at<HAS_A, HAS_N, false, 1, 4>(a, stream);
+    switch (a.step) {
+        case 1:  return launch_weighted_tile_at<HAS_A, HAS_N, true, 1, 4>(a, stream);
+        case 2:  return launch_weighted_tile_at<HAS_A, HAS_N, true, 2, 4>(a, stream);
+        case 4:  return launch_weighted_tile_at<HAS_A, HAS_N, true, 4, 4>(a, stream);
+        default: return launch_weighted_tile_at<HAS_A, HAS_N, true, 8, 4>(a, stream);
+    }
 }
 
 // ---- GAUSSIAN, radius R, step 1: separable.  out = sum_dy g(dy) [sum_dx g(dx) c(x+dx, y+dy)] / (hw(x) vw(y)) over the taps
@@ -378,12 +414,12 @@ int run_weighted_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStr
             RMD_LAUNCH_CHECK("gaussian_separable_kernel");
             continue;
         }
-        if (a.radius == 2 && a.step == 1 && tuning_env("RMD_WEIGHTED_TILE", 1)) {            // CROSS radius 2, WAVELET at spacing 1
-            if (a.albedo && a.normal) launch_weighted_tile<true, true>(a, stream);
-            else if (a.albedo)        launch_weighted_tile<true, false>(a, stream);
-            else if (a.normal)        launch_weighted_tile<false, true>(a, stream);
-            else                      launch_weighted_tile<false, false>(a, stream);
-            RMD_LAUNCH_CHECK("weighted_tile_kernel");
+        if (a.radius == 2 && a.step <= kTileMaxStep && tuning_env("RMD_WEIGHTED_TILE", 1)) {  // CROSS radius 2, WAVELET levels 0..3
+            const int rc = a.albedo && a.normal ? launch_weighted_tile<true, true>(a, stream)
+                         : a.albedo             ? launch_weighted_tile<true, false>(a, stream)
+                         : a.normal             ? launch_weighted_tile<false, true>(a, stream)
+                                                : launch_weighted_tile<false, false>(a, stream);
+            if (rc != RMD_OK) return rc;
             continue;
         }
         dim3 grid((W + 63) / 64, (H + 3) / 4);
