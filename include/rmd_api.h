@@ -386,6 +386,18 @@ int  rmd_event_destroy(void* event);
 int  rmd_event_record(void* event, void* stream);
 int  rmd_event_synchronize(void* event);   /* host waits for the event (e.g. an upload queued by openImages) */
 int  rmd_stream_wait_event(void* stream, void* event);
+/* hipGraph capture of whatever the caller queues on `stream` between begin and end (no counterpart in the reference: it
+   launches on the default stream, src/test.cu:76,88).  Every rmd_* launch entry point may be captured once it has run
+   eagerly on the device (the first call sets kernel attributes).  For a host whose own launch path is slow; the frame loop
+   of this package gains nothing from it (its six launches are queued ahead of the GPU anyway: 1080p 0.276 / 0.287 ms per
+   frame replayed against 0.287 / 0.271 eager in two runs, 4K 0.877 against 0.874, tools/graph_probe.py).  The graph holds
+   the POINTERS of the captured calls: capture an even number of frames of an rmd_svgf_context / SvgfDenoiser (its history
+   planes ping-pong) and keep the input planes in place.
+   `stream` must be a created stream, not NULL (the legacy default stream cannot be captured). */
+int  rmd_graph_capture_begin(void* stream);
+int  rmd_graph_capture_end(void* stream, void** graph);     /* ends the capture, instantiates; on failure the capture is ended and *graph = NULL */
+int  rmd_graph_launch(void* graph, void* stream);
+int  rmd_graph_destroy(void* graph);                         /* NULL allowed */
 int  rmd_device_sync(void);              /* reference cudaDeviceSynchronize(), src/test.cu:77,89 */
 int  rmd_device_count(int* count);
 int  rmd_set_device(int device);

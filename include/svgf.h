@@ -42,4 +42,19 @@ public:
     rmd_svgf_context* get() { return ctx; }
 };
 
+// hipGraph capture of whatever is queued on `stream` between begin() and end() (rmd_graph_* in rmd_api.h), for a host whose
+// own launch path is slow.  Capture an even number of SvgfContext frames (the history planes ping-pong) after at least one
+// eager frame, and keep the planes the captured calls named in place.
+class FrameGraph {
+    void* exec = nullptr;
+public:
+    FrameGraph() = default;
+    FrameGraph(const FrameGraph&) = delete;
+    FrameGraph& operator=(const FrameGraph&) = delete;
+    ~FrameGraph() { rmd_graph_destroy(exec); }
+    static void begin(void* stream) { rmdCheck(rmd_graph_capture_begin(stream), "FrameGraph::begin"); }
+    void end(void* stream) { rmd_graph_destroy(exec); exec = nullptr; rmdCheck(rmd_graph_capture_end(stream, &exec), "FrameGraph::end"); }
+    void launch(void* stream) { rmdCheck(rmd_graph_launch(exec, stream), "FrameGraph::launch"); }
+};
+
 #endif

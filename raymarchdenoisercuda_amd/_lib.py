@@ -152,6 +152,10 @@ SYMBOLS = {
     "rmd_event_record": (C.c_int, [_P, _P]),
     "rmd_event_synchronize": (C.c_int, [_P]),
     "rmd_stream_wait_event": (C.c_int, [_P, _P]),
+    "rmd_graph_capture_begin": (C.c_int, [_P]),
+    "rmd_graph_capture_end": (C.c_int, [_P, C.POINTER(_P)]),
+    "rmd_graph_launch": (C.c_int, [_P, _P]),
+    "rmd_graph_destroy": (C.c_int, [_P]),
     "rmd_device_sync": (C.c_int, []),
     "rmd_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rmd_set_device": (C.c_int, [C.c_int]),

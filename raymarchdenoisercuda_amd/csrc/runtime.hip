@@ -202,6 +202,41 @@ int rmd_stream_create(void** stream)
     return RMD_OK;
 }
 
+int rmd_graph_capture_begin(void* stream)
+{
+    if (!stream) return fail(RMD_E_NULL, "rmd_graph_capture_begin: the NULL stream cannot be captured (rmd_stream_create one)");
+    RMD_HIP(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+    return RMD_OK;
+}
+
+int rmd_graph_capture_end(void* stream, void** graph)
+{
+    if (!stream || !graph) return fail(RMD_E_NULL, "rmd_graph_capture_end: stream / graph is NULL");
+    *graph = nullptr;
+    hipGraph_t g = nullptr;
+    RMD_HIP(hipStreamEndCapture(as_stream(stream), &g));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) return hip_fail(e, "rmd_graph_capture_end: hipGraphInstantiate");
+    *graph = exec;
+    return RMD_OK;
+}
+
+int rmd_graph_launch(void* graph, void* stream)
+{
+    if (!graph) return fail(RMD_E_NULL, "rmd_graph_launch: graph is NULL");
+    RMD_HIP(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph), as_stream(stream)));
+    return RMD_OK;
+}
+
+int rmd_graph_destroy(void* graph)
+{
+    if (!graph) return RMD_OK;
+    RMD_HIP(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph)));
+    return RMD_OK;
+}
+
 int rmd_stream_destroy(void* stream)
 {
     if (!stream) return RMD_OK;

@@ -167,3 +167,53 @@ def test_frame_parts_are_refused_without_an_exchange_iteration(rmd, cuda):
     got = den2.denoise(c, nd, m)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("width,height", [(300, 200), (1920, 1080)])
+def test_frames_replayed_from_a_graph_equal_eager_frames(rmd, cuda, width, height):
+    """rmd_graph_*: two frames (the history planes ping-pong) captured on a side stream and replayed give bit for bit what
+    the same frame sequence gives eagerly."""
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    a, b = rmd.svgf.synth_gbuffer(width, height, 0), rmd.svgf.synth_gbuffer(width, height, 1)
+
+    eager = rmd.SvgfDenoiser(width, height, params=p)
+    want = torch.empty_like(a[0])
+    for _ in range(4):                                   # A B | A B A B A B
+        eager.denoise(*a, out=want)
+        eager.denoise(*b, out=want)
+    torch.cuda.synchronize()
+
+    den = rmd.SvgfDenoiser(width, height, params=p)
+    got = torch.empty_like(a[0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        den.denoise(*a, out=got)                         # eager: first use on this stream, history planes valid
+        den.denoise(*b, out=got)
+        side.synchronize()
+    with rmd.capture(side) as g:
+        den.denoise(*a, out=got)
+        den.denoise(*b, out=got)
+    side.synchronize()
+    assert not torch.equal(got, want)                    # the captured frames have not run
+    for _ in range(3):
+        g.launch()
+    side.synchronize()
+    assert torch.equal(got, want), f"{(got != want).sum().item()} values differ"
+    for x, y in zip(eager.history(), den.history()):
+        assert torch.equal(x, y)
+    g.destroy()
+    g.destroy()                                          # idempotent
+
+
+def test_graph_argument_errors(rmd, cuda):
+    import ctypes as C
+    with pytest.raises(ValueError):
+        rmd.capture(torch.cuda.default_stream())
+    assert rmd.lib.rmd_graph_capture_begin(None) == -1                     # RMD_E_NULL: the legacy default stream
+    assert rmd.lib.rmd_graph_launch(None, None) == -1
+    assert rmd.lib.rmd_graph_destroy(None) == 0
+    h = C.c_void_p()
+    side = torch.cuda.Stream()
+    assert rmd.lib.rmd_graph_capture_end(C.c_void_p(side.cuda_stream), C.byref(h)) != 0        # no capture in progress
+    assert not h
