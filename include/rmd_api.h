@@ -229,6 +229,18 @@ int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int r
 int rmd_svgf_frame_tv(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream);
 int rmd_svgf_frame_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
                           void* history_ready_event);
+/* Frame pipelining INSIDE the a-trous waves: the iterations of frame `f` behind hist_iteration carry the temporal pass of
+ * frame `next` as a side job (one 64x4 tile per workgroup every few steps; T is HBM-bound with a half idle VALU, the iterations
+ * are VALU-bound with HBM at 40 %, and as a side job T needs no registers of its own beside three a-trous workgroups per CU);
+ * the tiles they leave over and V(next) follow as launches of their own.  On return (in stream order) `next` is where
+ * rmd_svgf_frame_tv(next, ...) would have left it -- same kernel code, same bits -- and the caller continues with
+ * rmd_svgf_frame_atrous[_next](next, ...).  `next` names the planes of the following frame: hist_color = f->hist_color_out,
+ * hist_moments = f->t_moments, prev_nd = f->nd; the planes T / V(next) write (t_color, t_moments, v_color, t_debug) must be none
+ * of f's ping / out_color / hist_color_out / nd.  Whole frames or strips without a mid-frame exchange, no statistics.
+ * MEASURED AND LOST (4K: 0.999 ms per frame against 0.877-0.906 serial): part of the experiments build
+ * only (rmd_has_experiments()); the product library returns RMD_E_UNSUPPORTED. */
+int rmd_svgf_frame_atrous_next(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
+                               void* history_ready_event, const rmd_svgf_frame_desc* next);
 /* The a-trous iterations of a strip whose params name an exchange_iteration X, in the three parts the exchange cuts them into:
  *   RMD_ATROUS_HEAD      iterations 0..X-1, then iteration X on the BOUNDARY rows of the strip: the rows rank +-1 is waiting
  *                        for (rmd_svgf_frame_mid_exchange()[1] rows at each end that is not a frame edge).  Then the caller

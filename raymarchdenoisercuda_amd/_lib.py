@@ -101,6 +101,8 @@ SYMBOLS = {
     "rmd_svgf_frame": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
     "rmd_svgf_frame_tv": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
     "rmd_svgf_frame_atrous": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P, _P]),
+    "rmd_svgf_frame_atrous_next": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P, _P,
+                                             C.POINTER(SvgfFrameDesc)]),
     "rmd_svgf_frame_atrous_part": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P, _P, C.c_int]),
     "rmd_svgf_frame_mid_exchange": (C.c_int, [C.POINTER(SvgfParams), C.POINTER(C.c_int * 2)]),
     "rmd_svgf_frame_iteration_reach": (C.c_int, [C.POINTER(SvgfParams), C.POINTER(C.c_int * 8)]),

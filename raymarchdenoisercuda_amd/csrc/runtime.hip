@@ -35,6 +35,9 @@ int fail(int code, const char* fmt, ...)
 int hip_fail(hipError_t e, const char* what)
 {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    // The error has been reported through the return value: take it out of the runtime's per-thread "last error", or the next
+    // hipGetLastError() of anybody in the process (torch checks after each of its launches) blames an innocent call for it.
+    (void)hipGetLastError();
     return (int)e;
 }
 
@@ -67,6 +70,24 @@ int current_device()
 {
     int d = -1;
     return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+
+// Work counters of rmd_svgf_frame_atrous_next: a block of 64 words per device, handed out round robin (a counter is in use from
+// the call's memset to the end of its last launch; 64 calls later it is long done)
+unsigned* side_counter_on_device()
+{
+    static std::mutex mu;
+    static unsigned* block[kMaxDevices] = {};
+    static unsigned next[kMaxDevices] = {};
+    const int d = current_device();
+    if (d < 0 || d >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!block[d]) {
+        void* q = nullptr;
+        if (hipMalloc(&q, 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
+        block[d] = static_cast<unsigned*>(q);
+    }
+    return block[d] + (next[d]++ % 64u);
 }
 
 int device_cus()

@@ -37,6 +37,7 @@
 //     blue is accumulated through lum and recovered at the end, b = (L - .2126R - .7152G)/.0722
 //   - normals are unit length by contract, so max(0, n.n) is applied as a [0,1] clamp.
 #include "common.h"
+#include "svgf_tv.h"
 #include <type_traits>
 
 namespace rmd {
@@ -70,6 +71,14 @@ struct AtrousArgs {
     int b_row0, b_row1, b_band_h, b_band_base, b_nblocks, b_n_hi, b_band_h_hi, b_nblocks_hi;
     int cus;       // CUs the launch may count on (rmd_svgf_params.atrous_cus or the whole device)
     int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
+#ifdef RMD_EXPERIMENTS
+    // SIDE JOB (stream kernel, rmd_svgf_frame_atrous_next; measured and lost): the temporal pass of the
+    // NEXT frame, one 64x4 tile per workgroup every side_every steps, tiles claimed from a device counter (units 0 ..
+    // side_units-1 = the tiles of `side`'s rows, row major).  side_units = 0: none.
+    TemporalArgs side;
+    unsigned* side_counter;
+    int side_units, side_every;
+#endif
 };
 
 // log2 of the B3-spline taps {3/8, 1/4, 1/16} (reference src/filter.cu:10)
@@ -732,23 +741,64 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
 #ifdef RMD_ATROUS_TRACE
     unsigned long long ph[5] = { 0, 0, 0, 0, 0 }, tp = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef RMD_EXPERIMENTS
+    // Side job (experiments build): every side_every-th step the workgroup also runs one 64x4 tile of the NEXT frame's
+    // temporal pass (thread = pixel, temporal_tile: the standalone pass's code and bits).  That pass is HBM-bound with a half
+    // idle VALU, this one VALU-bound with HBM at 40 %; as waves of their own they find no registers beside three a-trous
+    // workgroups, as a side job of these waves they need none: between two steps only the loop state is live (+10 VGPRs).
+    // The tile is claimed (one atomic by thread 0) at the top of the step and its number handed to the workgroup through LDS
+    // behind the step's second barrier, so nobody waits for the atomic.  MEASURED AND LOST: the four
+    // waves of the workgroup sit through three dependent memory round trips per tile, and the two workgroups left on the CU
+    // cannot fill its VALUs meanwhile: a tile costs 9.9 ns of frame time here against 5.7 ns in the pass's own launch.
+    unsigned* const side_slot = reinterpret_cast<unsigned*>(lds + C::LDS_BYTES);
+    const bool side_on = a.side_units > 0;
+    int side_phase = side_on ? (int)(blockIdx.x % (unsigned)a.side_every) : 0;     // workgroups of a CU take their turns apart
+    auto side_tile = [&](const unsigned u) {
+        if (u < (unsigned)a.side_units) {
+            const int tx = (int)(u % (unsigned)a.side.tiles_x), ty = (int)(u / (unsigned)a.side.tiles_x);
+            temporal_tile(a.side, tx, a.side.row0 / 4 + ty);
+        }
+    };
+#endif
     for (int j = j0; j < jhi; j += C::ADV) {
         if (j >= jq3)      __builtin_amdgcn_s_setprio(0);
         else if (j >= jq2) __builtin_amdgcn_s_setprio(1);
         else if (j >= jq1) __builtin_amdgcn_s_setprio(2);
         const bool more = j + C::ADV < jhi;
+#ifdef RMD_EXPERIMENTS
+        const bool side_now = side_on && side_phase == 0;                          // workgroup-uniform
+        side_phase = side_phase == 0 ? a.side_every - 1 : side_phase - 1;
+        unsigned claim = 0u;
+        if (side_now && tid == 0) claim = atomicAdd(a.side_counter, 1u);
+#endif
         if (EDGE && more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute (interior form: inside compute)
         RMD_PHASE(0)
         compute(j);
         RMD_PHASE(1)
-        if (!more) { write_out(j); break; }
+        if (!more) {
+            write_out(j);
+#ifdef RMD_EXPERIMENTS
+            if (side_now) {
+                if (tid == 0) *side_slot = claim;
+                __syncthreads();
+                side_tile(*side_slot);
+            }
+#endif
+            break;
+        }
         __syncthreads();                                     // every wave is done reading the ADV oldest rows
         RMD_PHASE(2)
         store_rows(j - 2 + C::NR); store_aux();
         write_out(j);
+#ifdef RMD_EXPERIMENTS
+        if (side_now && tid == 0) *side_slot = claim;
+#endif
         RMD_PHASE(3)
         __syncthreads();
         RMD_PHASE(4)
+#ifdef RMD_EXPERIMENTS
+        if (side_now) side_tile(*side_slot);                 // (ends with a barrier of its own when the pass keeps tile flags)
+#endif
     }
 #ifdef RMD_ATROUS_TRACE
     if (tid == 0 && blockIdx.x < 8192)
@@ -913,8 +963,8 @@ static int launch_planned(const AtrousArgs& a, hipStream_t stream)
     // attribute (NP = 1 at step 16 asks for 65 568 bytes of LDS) on every one of them
     if (first_use_on_device(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>)))
         RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S, NP>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES, stream, a);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S, NP>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES + 16, stream, a);   // + the side job's slot
     RMD_LAUNCH_CHECK("atrous_stream_kernel");
     return RMD_OK;
 }
@@ -985,6 +1035,9 @@ extern "C" int rmd_debug_atrous_plan(int width, int height, int row0, int row1, 
     a.row0 = row0; a.row1 = row1; a.step = 1 << iteration; a.cus = cus;
     a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
     a.b_row0 = a.b_row1 = a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
+#ifdef RMD_EXPERIMENTS
+    a.side_units = 0;
+#endif
     switch (iteration) {
         case 0: plan_stream<1, 2>(a); break;
         case 1: plan_stream<2, 2>(a); break;
@@ -1017,6 +1070,12 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
 extern "C" int rmd_svgf_atrous2(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
                                 const float* in, float* out, int row0, int row1, int row0b, int row1b, void* stream)
 {
+    return launch_atrous(f, p, iteration, in, out, row0, row1, row0b, row1b, stream, nullptr);
+}
+
+int rmd::launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration, const float* in, float* out,
+                       int row0, int row1, int row0b, int row1b, void* stream, const AtrousSide* side)
+{
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_atrous: params is NULL");
     if (!in || !out || !f->nd) return fail(RMD_E_NULL, "rmd_svgf_atrous: in/out/nd plane is NULL");
@@ -1029,7 +1088,9 @@ extern "C" int rmd_svgf_atrous2(const rmd_svgf_frame_desc* f, const rmd_svgf_par
     if (int e = check_rows_in_buffer(f, row0 - 2 * s, row1 + 2 * s, "rmd_svgf_atrous")) return e;
     const bool two = row1b > row0b;
     // only the default row-streaming kernel takes two row ranges in one launch; every other form runs them one after the other
-    if (two && !((p->atrous_variant == 0 || p->atrous_variant == 3) && iteration <= 4)) {
+    const bool streams = (p->atrous_variant == 0 || p->atrous_variant == 3) && iteration <= 4;
+    if (side && !streams) return fail(RMD_E_UNSUPPORTED, "rmd_svgf_frame_atrous_next: only the row-streaming a-trous kernel (atrous_variant 0, iterations 0..4) carries a side job");
+    if (two && !streams) {
         if (int e = rmd_svgf_atrous(f, p, iteration, in, out, row0, row1, stream)) return e;
         return rmd_svgf_atrous(f, p, iteration, in, out, row0b, row1b, stream);
     }
@@ -1051,6 +1112,12 @@ extern "C" int rmd_svgf_atrous2(const rmd_svgf_frame_desc* f, const rmd_svgf_par
     a.b_row0 = two ? row0b : 0; a.b_row1 = two ? row1b : 0;
     a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
     a.nt_out = (double)(row1 - row0 + (two ? row1b - row0b : 0)) * f->width * 48.0 > 256.0e6 ? 1 : 0;
+#ifdef RMD_EXPERIMENTS
+    a.side_units = 0; a.side_every = 1; a.side_counter = nullptr;
+    if (side && side->units > 0) { a.side = side->t; a.side_counter = side->counter; a.side_units = side->units; a.side_every = side->every < 1 ? 1 : side->every; }
+#else
+    if (side) return fail(RMD_E_UNSUPPORTED, "rmd_svgf_frame_atrous_next is an experiment (make experiments; rmd_has_experiments() == 0 here)");
+#endif
     if (p->atrous_cus < 0) return fail(RMD_E_PARAM, "rmd_svgf_atrous: atrous_cus %d is negative", p->atrous_cus);
     a.cus = p->atrous_cus > 0 && p->atrous_cus < device_cus() ? p->atrous_cus : device_cus();
 

@@ -10,6 +10,7 @@
 // passes tap (redundant rows instead of one halo exchange per pass); results are
 // bit-identical to a whole-frame run because every pixel sees the same inputs and arithmetic.
 #include "common.h"
+#include "svgf_tv.h"
 #include <vector>
 
 namespace rmd {
@@ -182,6 +183,68 @@ int rmd_svgf_frame_iteration_plane(const rmd_svgf_frame_desc* f, const rmd_svgf_
     const float* in;
     atrous_route(f, p, iteration, &in, plane);
     return RMD_OK;
+}
+
+// EXPERIMENTS BUILD (measured and lost).
+// The a-trous iterations of frame `f` with the temporal pass of the NEXT frame as their side job (svgf_atrous.hip): the
+// iterations behind hist_iteration (whose output T(next) reads as history) carry one 64x4 tile of T(next) per workgroup every
+// few steps; what they leave over runs as a launch of its own, then V(next).  Afterwards `next` is where rmd_svgf_frame_tv
+// would have left it: the caller goes on with rmd_svgf_frame_atrous[_next](next, ...).
+int rmd_svgf_frame_atrous_next(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
+                               void* history_ready_event, const rmd_svgf_frame_desc* next)
+{
+#ifndef RMD_EXPERIMENTS
+    (void)f; (void)p; (void)row0; (void)row1; (void)stream; (void)history_ready_event; (void)next;
+    return fail(RMD_E_UNSUPPORTED, "rmd_svgf_frame_atrous_next is an experiment that lost (DESIGN.md section 4.7): make experiments; rmd_has_experiments() == 0 here");
+#else
+    Reach r;
+    if (int e = check_frame_call(f, p, row0, row1, r)) return e;
+    if (!next) return fail(RMD_E_NULL, "rmd_svgf_frame_atrous_next: next is NULL");
+    if (int e = check_frame_call(next, p, row0, row1, r)) return e;
+    if (r.mid >= 0) return fail(RMD_E_PARAM, "rmd_svgf_frame_atrous_next: not with a mid-frame exchange (exchange_iteration >= 0)");
+    if (next->stats) return fail(RMD_E_PARAM, "rmd_svgf_frame_atrous_next: statistics frames run T and V on their own (rmd_svgf_frame_tv)");
+    if (p->tv_workgroups != 0) return fail(RMD_E_PARAM, "rmd_svgf_frame_atrous_next: tv_workgroups must be 0");
+    if (next->width != f->width || next->height != f->height || next->buf_row0 != f->buf_row0 || next->buf_rows != f->buf_rows)
+        return fail(RMD_E_SHAPE, "rmd_svgf_frame_atrous_next: the two frames differ in geometry");
+    // what T(next) and V(next) write must be none of the planes the carrying iterations still read or write
+    const void* busy[] = { f->ping[0], f->ping[1], f->out_color, f->hist_color_out, f->nd };
+    const void* written[] = { next->t_color, next->t_moments, next->v_color, next->t_debug };
+    for (const void* w : written)
+        for (const void* b : busy)
+            if (w && w == b) return fail(RMD_E_BUFFER, "rmd_svgf_frame_atrous_next: a plane T / V of the next frame write is still in use by this frame's iterations");
+    const int H = f->height, n = p->iterations;
+    const int t0 = clampi(row0 - r.t, 0, H), t1 = clampi(row1 + r.t, 0, H);
+    const int v0 = clampi(row0 - r.v, 0, H), v1 = clampi(row1 + r.v, 0, H);
+    const bool sparse = variance_reads_sparse_t_color(next, p, true);
+    AtrousSide side;
+    if (int e = make_temporal_args(next, p, t0, t1, true, sparse, &side.t)) return e;
+    side.units = side.t.tiles_x * ((t1 - 1) / 4 - t0 / 4 + 1);
+    side.counter = side_counter_on_device();
+    if (!side.counter) return hip_fail(hipErrorOutOfMemory, "rmd_svgf_frame_atrous_next: device counter");
+    RMD_HIP(hipMemsetAsync(side.counter, 0, sizeof(unsigned), as_stream(stream)));
+    // one tile per workgroup every `every` steps: the carrying launches' steps (512 pixels each) over the tiles
+    double steps = 0.0;
+    for (int i = p->hist_iteration + 1; i < n && i <= 4; ++i)
+        steps += (double)(clampi(row1 + r.atrous[i], 0, H) - clampi(row0 - r.atrous[i], 0, H)) * f->width / 512.0;
+    side.every = steps >= side.units ? (int)(steps / side.units) : 1;
+    for (int i = 0; i < n; ++i) {
+        const float* in;
+        float* out;
+        atrous_route(f, p, i, &in, &out);
+        const int a0 = clampi(row0 - r.atrous[i], 0, H), a1 = clampi(row1 + r.atrous[i], 0, H);
+        const bool carries = i > p->hist_iteration && i <= 4 && p->atrous_variant == 0;
+        if (int e = launch_atrous(f, p, i, in, out, a0, a1, 0, 0, stream, carries ? &side : nullptr)) return e;
+        if (i == n - 1 && i == p->hist_iteration && f->hist_color_out != out) {
+            const size_t off = (size_t)(a0 - f->buf_row0) * f->width * 4;
+            RMD_HIP(hipMemcpyAsync(f->hist_color_out + off, out + off, (size_t)(a1 - a0) * f->width * 16,
+                                   hipMemcpyDeviceToDevice, as_stream(stream)));
+        }
+        if (i == p->hist_iteration && history_ready_event)
+            RMD_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(history_ready_event), as_stream(stream)));
+    }
+    if (int e = launch_temporal_claim(side, stream)) return e;
+    return launch_variance(next, p, v0, v1, stream, true, sparse);
+#endif
 }
 
 int rmd_svgf_frame_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,

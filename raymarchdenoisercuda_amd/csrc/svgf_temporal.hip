@@ -15,35 +15,6 @@
 
 namespace rmd {
 
-// One 64x4 tile of the GLOBAL tiling (rows 4k..4k+3, so T and V agree on tiles) by one workgroup.
-__device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int tile_x, const int tile_y)
-{
-    const Geom g = a.g;
-    const int x = tile_x * 64 + (threadIdx.x & 63);
-    const int y = tile_y * 4 + (threadIdx.x >> 6);
-    bool short_history = false;
-    const bool active = x < g.W && y >= a.row0 && y < a.row1;
-    float4 tc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    size_t i = 0;
-    if (active) {
-        i = pix_index(g, x, y);
-        float4 mom;
-        int4 dbg;
-        temporal_pixel(a, x, y, tc, mom, dbg);
-        if (!a.sparse_t_color) a.t_color[i] = tc;
-        if (a.v_color) a.v_color[i] = tc;
-        a.t_moments[i] = mom;
-        if (a.t_debug) a.t_debug[i] = dbg;
-        short_history = dbg.w < a.var_h_threshold;
-    }
-    if (a.tile_flags) {
-        const int any = __syncthreads_or(short_history ? 1 : 0);
-        if (threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + tile_x] = (unsigned char)(any != 0);
-        // 16 of T's 136 B per pixel: in the steady state ~2 % of the tiles are flagged
-        if (a.sparse_t_color && any && active) a.t_color[i] = tc;
-    }
-}
-
 // Whole frames (rmd_svgf_frame_tv): T and V in ONE launch.  V rewrites only the pixels with a short history (~10 k of 8.3 M
 // at 4K in the steady state, in ~2 % of the tiles), but as a launch of its own it cost 26-30 us at EVERY frame size -- an empty
 // grid, a flag scan, a dependent chain of loads per flagged tile (10 % of a 1080p frame).  Here the workgroup that finds a
@@ -159,6 +130,20 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     temporal_tile(a, blockIdx.x, a.row0 / 4 + blockIdx.y);
 }
 
+// Tiles claimed from a device counter shared with the a-trous launches that carried the pass as a side job
+__global__ __launch_bounds__(256) void svgf_temporal_claim_kernel(TemporalArgs a, unsigned* counter, int units)
+{
+    __shared__ unsigned slot;
+    for (;;) {
+        if (threadIdx.x == 0) slot = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned u = slot;
+        if (u >= (unsigned)units) return;                 // workgroup-uniform
+        temporal_tile(a, (int)(u % (unsigned)a.tiles_x), a.row0 / 4 + (int)(u / (unsigned)a.tiles_x));
+        __syncthreads();                                  // everybody has read the slot (a pass without tile flags has no barrier of its own)
+    }
+}
+
 #ifdef RMD_EXPERIMENTS
 // A fixed, small number of workgroups (one per CU) that walk over the tiles: the form that runs
 // UNDERNEATH the a-trous launches of the previous frame (rmd_svgf_params.tv_workgroups).  Three
@@ -184,8 +169,8 @@ __global__ __launch_bounds__(256) void svgf_temporal_persistent_kernel(TemporalA
 
 using namespace rmd;
 
-int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused,
-                         bool sparse_t_color)
+int rmd::make_temporal_args(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, bool fused, bool sparse_t_color,
+                            TemporalArgs* out)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_temporal: params is NULL");
@@ -225,6 +210,15 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     a.row0 = row0; a.row1 = row1;
     a.alpha_color = p->alpha_color; a.alpha_moments = p->alpha_moments; a.k_z = p->k_z; a.k_n = p->k_n;
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
+    *out = a;
+    return RMD_OK;
+}
+
+int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream, bool fused,
+                         bool sparse_t_color)
+{
+    TemporalArgs a;
+    if (int e = make_temporal_args(f, p, row0, row1, fused, sparse_t_color, &a)) return e;
     dim3 grid((f->width + 63) / 64, (row1 - 1) / 4 - row0 / 4 + 1);
     if (p->tv_workgroups > 0) {
 #ifdef RMD_EXPERIMENTS
@@ -236,6 +230,17 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
         hipLaunchKernelGGL(svgf_temporal_kernel, grid, dim3(256), 0, as_stream(stream), a);
     }
     RMD_LAUNCH_CHECK("svgf_temporal_kernel");
+    return RMD_OK;
+}
+
+// What the a-trous launches did not get to (rmd_svgf_frame_atrous_next): every workgroup claims tiles from the same counter
+// until it runs out.  Nobody waits for anybody; a launch that finds the counter at `units` returns at once.
+int rmd::launch_temporal_claim(const AtrousSide& side, void* stream)
+{
+    if (side.units <= 0) return RMD_OK;
+    const int wgs = side.units < 8 * device_cus() ? side.units : 8 * device_cus();
+    hipLaunchKernelGGL(svgf_temporal_claim_kernel, dim3(wgs), dim3(256), 0, as_stream(stream), side.t, side.counter, side.units);
+    RMD_LAUNCH_CHECK("svgf_temporal_claim_kernel");
     return RMD_OK;
 }
 

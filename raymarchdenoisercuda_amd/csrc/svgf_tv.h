@@ -21,6 +21,24 @@ struct TemporalArgs {
     int h_max, max_motion_rows;
 };
 
+// The temporal pass of the NEXT frame as a side job of the a-trous launches of this one (svgf_atrous.hip,
+// rmd_svgf_frame_atrous_next): its tiles, row major over `t`'s rows, are claimed from `counter`.
+struct AtrousSide {
+    TemporalArgs t;
+    unsigned* counter;     // device word, zero before the first launch that carries the job
+    int units;             // tiles_x * tile rows of [t.row0, t.row1)
+    int every;             // one tile per workgroup every `every` steps
+};
+
+// validates the T call and fills the kernel arguments (launch_temporal's; `fused`: v_color + tile flags as in rmd_svgf_frame_tv)
+int make_temporal_args(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, bool fused, bool sparse_t_color,
+                       TemporalArgs* out);
+// the tiles of `side` nobody has claimed yet (a grid of workgroups that claim until the counter runs out)
+int launch_temporal_claim(const AtrousSide& side, void* stream);
+int launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration, const float* in, float* out,
+                  int row0, int row1, int row0b, int row1b, void* stream, const AtrousSide* side);
+unsigned* side_counter_on_device();        // one zero-initialised word per device (runtime.hip)
+
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 
 // Appendix A.T for ONE pixel (x, y) inside the frame and the buffer: returns c' + variance in `tc`, the moments in `mom`,
@@ -116,6 +134,35 @@ __device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int 
     tc = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
     mom = make_float4(m1, m2, (float)h, 0.0f);
     dbg = make_int4(q0x, q0y, mask, h);
+}
+
+// One 64x4 tile of the GLOBAL tiling (rows 4k..4k+3, so T and V agree on tiles) by one workgroup.
+__device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int tile_x, const int tile_y)
+{
+    const Geom g = a.g;
+    const int x = tile_x * 64 + (threadIdx.x & 63);
+    const int y = tile_y * 4 + (threadIdx.x >> 6);
+    bool short_history = false;
+    const bool active = x < g.W && y >= a.row0 && y < a.row1;
+    float4 tc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    size_t i = 0;
+    if (active) {
+        i = pix_index(g, x, y);
+        float4 mom;
+        int4 dbg;
+        temporal_pixel(a, x, y, tc, mom, dbg);
+        if (!a.sparse_t_color) a.t_color[i] = tc;
+        if (a.v_color) a.v_color[i] = tc;
+        a.t_moments[i] = mom;
+        if (a.t_debug) a.t_debug[i] = dbg;
+        short_history = dbg.w < a.var_h_threshold;
+    }
+    if (a.tile_flags) {
+        const int any = __syncthreads_or(short_history ? 1 : 0);
+        if (threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + tile_x] = (unsigned char)(any != 0);
+        // 16 of T's 136 B per pixel: in the steady state ~2 % of the tiles are flagged
+        if (a.sparse_t_color && any && active) a.t_color[i] = tc;
+    }
 }
 
 constexpr int kVR = 3, kVW = 64 + 2 * kVR, kVH = 4 + 2 * kVR;      // a 64x4 tile + the 3-pixel reach of the 7x7 window: 70 x 10

@@ -179,6 +179,8 @@ class SvgfDenoiser:
         self.tile_flags = torch.zeros(tile_flags_bytes(width, height), dtype=torch.uint8, device=device)
         self.cur = 0
         self.has_history = False
+        self._tv_done_for = None     # data pointers of the frame whose T + V the previous call already ran (next_frame)
+        self._keep_next = None
         self.prev_nd = None
         self.pipelined = pipelined
         self._ev_hist = C.c_void_p()
@@ -202,6 +204,7 @@ class SvgfDenoiser:
     def reset_history(self):
         self.has_history = False
         self.prev_nd = None
+        self._tv_done_for = None
 
     def history(self):
         """(hist_color, hist_moments) the NEXT denoise call reads."""
@@ -214,16 +217,20 @@ class SvgfDenoiser:
         else:
             torch.cuda.current_stream().synchronize()
 
-    def describe(self, color, nd, motion, out):
-        use_hist = self.has_history and self.prev_nd is not None
+    def describe(self, color, nd, motion, out, ahead=False):
+        """The frame descriptor of the next denoise call -- or, with ahead=True, of the call AFTER it (its history planes are
+        the ones the next call writes, its prev_nd the next call's nd: pass that as `ahead`)."""
+        cur = self.cur ^ 1 if ahead is not False else self.cur
+        prev_nd = ahead if ahead is not False else self.prev_nd
+        use_hist = ahead is not False or (self.has_history and self.prev_nd is not None)
         return frame_desc(
             self.width, self.height, self.buf_row0, self.buf_rows,
             color=color, nd=nd, motion=motion,
-            hist_color=self.hist_color[self.cur] if use_hist else None,
-            hist_moments=self.hist_moments[self.cur] if use_hist else None,
-            prev_nd=self.prev_nd if use_hist else None,
-            t_color=self.t_color, t_moments=self.hist_moments[self.cur ^ 1], t_debug=self.t_debug,
-            v_color=self.v_color, hist_color_out=self.hist_color[self.cur ^ 1],
+            hist_color=self.hist_color[cur] if use_hist else None,
+            hist_moments=self.hist_moments[cur] if use_hist else None,
+            prev_nd=prev_nd if use_hist else None,
+            t_color=self.t_color, t_moments=self.hist_moments[cur ^ 1], t_debug=self.t_debug,
+            v_color=self.v_color, hist_color_out=self.hist_color[cur ^ 1],
             ping=(self.ping[0], self.ping[1]), out_color=out, stats=self.stats, tile_flags=self.tile_flags)
 
     def iteration_plane(self, iteration, out=None):
@@ -238,7 +245,7 @@ class SvgfDenoiser:
                 dst, pp = self.ping[pp], pp ^ 1
         return dst
 
-    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None, hooks=None):
+    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None, hooks=None, next_frame=None):
         """One frame.  `nd` is borrowed until the next call (it becomes prev_nd).  `before_tv` is
         called just before T is launched, on the stream T runs on (a row-strip deployment completes
         its history halo there).  Serial form: runs on `stream` (default: torch's current stream).
@@ -256,7 +263,26 @@ class SvgfDenoiser:
         row0 = max(self.buf_row0, 0) if row0 is None else row0
         row1 = min(self.buf_row0 + self.buf_rows, self.height) if row1 is None else row1
         d = self.describe(color, nd, motion, out)
-        if not self.pipelined:
+        # next_frame = (color, nd, motion) of the FOLLOWING call (serial form, no hooks): its temporal pass rides inside this
+        # frame's a-trous launches (rmd_svgf_frame_atrous_next) and the following call then skips T + V
+        tv_done = self._tv_done_for is not None
+        if tv_done and self._tv_done_for != tuple(t.data_ptr() for t in (color, nd, motion)):
+            raise ValueError("the previous denoise() call ran this frame's temporal pass on the planes it was given as next_frame; "
+                             "call denoise() with those planes")
+        self._tv_done_for = None
+        if next_frame is not None:
+            if self.pipelined or hooks is not None or before_tv is not None or frame_mid_exchange(self.params)[0] >= 0:
+                raise ValueError("next_frame needs the serial frame without hooks or a mid-frame exchange")
+            s_ptr = _stream_ptr(torch.cuda.current_stream() if stream is None else stream)
+            p = self.params
+            if not tv_done:
+                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(p), row0, row1, s_ptr))
+            nc, nnd, nm = next_frame
+            dn = self.describe(nc, nnd, nm, out, ahead=nd)
+            check(lib.rmd_svgf_frame_atrous_next(C.byref(d), C.byref(p), row0, row1, s_ptr, None, C.byref(dn)))
+            self._tv_done_for = tuple(t.data_ptr() for t in (nc, nnd, nm))
+            self._keep_next = next_frame                 # the planes stay referenced until the following call
+        elif not self.pipelined:
             if before_tv is not None:
                 before_tv()
             # the caller's CURRENT torch stream unless told otherwise (NULL would be unordered with a
@@ -267,7 +293,8 @@ class SvgfDenoiser:
             # the history-ready event only where somebody waits for it (a row-strip deployment): an event record between two
             # launches costs ~6 us of idle GPU on this stack (tools/frame_gaps.py)
             ev_hist = self._ev_hist if hooks is not None and hasattr(hooks, "hist_ready") else None
-            check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(p), row0, row1, s_ptr))
+            if not tv_done:
+                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(p), row0, row1, s_ptr))
             if mid < 0:
                 check(lib.rmd_svgf_frame_atrous(C.byref(d), C.byref(p), row0, row1, s_ptr, ev_hist))
                 if hooks is not None and hasattr(hooks, "hist_ready"):
@@ -288,6 +315,8 @@ class SvgfDenoiser:
                 if p.hist_iteration > mid and hooks is not None and hasattr(hooks, "hist_ready"):
                     hooks.hist_ready(ev_hist)
         else:
+            if tv_done:
+                raise ValueError("next_frame and the pipelined form do not mix")
             if frame_mid_exchange(self.params)[0] >= 0:
                 raise ValueError("exchange_iteration >= 0 needs the serial (single-stream) frame: pipelined=False")
             sa, sb = self.stream_a, self.stream_b

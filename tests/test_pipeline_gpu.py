@@ -217,3 +217,38 @@ def test_graph_argument_errors(rmd, cuda):
     side = torch.cuda.Stream()
     assert rmd.lib.rmd_graph_capture_end(C.c_void_p(side.cuda_stream), C.byref(h)) != 0        # no capture in progress
     assert not h
+
+
+@pytest.mark.experiments
+@pytest.mark.parametrize("width,height", [(300, 200), (1920, 1080)])
+def test_next_frames_temporal_pass_inside_the_atrous_launches(rmd, cuda, width, height):
+    """rmd_svgf_frame_atrous_next (experiments build; it lost on time): the temporal pass of frame k+1
+    as a side job of frame k's a-trous launches gives the serial frames bit for bit, whoever ends up running a tile."""
+    p = rmd.default_params()
+    p.max_motion_rows = 8
+    frames = 6
+    serial, den_s = run_sequence(rmd, width, height, frames, False, p)
+    inputs = [rmd.svgf.synth_gbuffer(width, height, f) for f in range(frames)]
+    den = rmd.SvgfDenoiser(width, height, params=p)
+    outs = [torch.empty_like(inputs[0][0]) for _ in range(frames)]
+    for f in range(frames):
+        den.denoise(*inputs[f], out=outs[f], next_frame=inputs[f + 1] if f + 1 < frames else None)
+    torch.cuda.synchronize()
+    for f, (a, b) in enumerate(zip(serial, outs)):
+        assert torch.equal(a, b), f"frame {f}: {(a != b).sum().item()} values differ"
+    for a, b in zip(den_s.history(), den.history()):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):                       # the frame announced as next_frame must be the one that follows
+        den.denoise(*inputs[0], out=outs[0], next_frame=inputs[1])
+        den.denoise(*inputs[2], out=outs[2])
+
+
+def test_next_frame_side_job_is_refused_by_the_product_build(rmd, cuda):
+    if rmd.HAS_EXPERIMENTS:
+        pytest.skip("experiments build")
+    p = rmd.default_params()
+    den = rmd.SvgfDenoiser(128, 64, params=p)
+    a, b = rmd.svgf.synth_gbuffer(128, 64, 0), rmd.svgf.synth_gbuffer(128, 64, 1)
+    with pytest.raises(rmd.RmdError) as e:
+        den.denoise(*a, next_frame=b)
+    assert e.value.code == -6
