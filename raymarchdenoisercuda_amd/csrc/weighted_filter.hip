@@ -232,10 +232,21 @@ __global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel
         }
     };
     if (inside) window(std::true_type{}); else window(std::false_type{});
-    // the centre tap has weight k(0,0) > 0, so sw > 0
-    a.out[(size_t)yA * a.W + x] = make_uchar4((unsigned char)(sr.x / sw.x), (unsigned char)(sg.x / sw.x), (unsigned char)(sb.x / sw.x), 0);
+    // The six quotients s / sw as the compiler expands an IEEE division (reciprocal, one Newton step, two residual corrections
+    // of the quotient), packed for the two pixels and with the reciprocal shared by the three channels; without the operand
+    // scaling of v_div_scale / v_div_fixup, which is the identity here: the centre tap has weight k(0,0) > 0 and a weight is
+    // at most 1, so sw lies in [2^-9, 25] and the sums in [0, 6375].  Same bits as `/` (the 4K test against the gather kernel).
+    wf2 rcp = { __builtin_amdgcn_rcpf(sw.x), __builtin_amdgcn_rcpf(sw.y) };
+    rcp = __builtin_elementwise_fma(__builtin_elementwise_fma(-sw, rcp, wf2{ 1.0f, 1.0f }), rcp, rcp);
+    auto quotient = [&](const wf2 n) {
+        wf2 q = n * rcp;
+        q = __builtin_elementwise_fma(__builtin_elementwise_fma(-sw, q, n), rcp, q);
+        return __builtin_elementwise_fma(__builtin_elementwise_fma(-sw, q, n), rcp, q);
+    };
+    const wf2 qr = quotient(sr), qg = quotient(sg), qb = quotient(sb);
+    a.out[(size_t)yA * a.W + x] = make_uchar4((unsigned char)qr.x, (unsigned char)qg.x, (unsigned char)qb.x, 0);
     if (yB < a.H)
-        a.out[(size_t)yB * a.W + x] = make_uchar4((unsigned char)(sr.y / sw.y), (unsigned char)(sg.y / sw.y), (unsigned char)(sb.y / sw.y), 0);
+        a.out[(size_t)yB * a.W + x] = make_uchar4((unsigned char)qr.y, (unsigned char)qg.y, (unsigned char)qb.y, 0);
 }
 
 constexpr int kTileMaxStep = 8;
