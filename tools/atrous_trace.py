@@ -78,5 +78,16 @@ for it in range(5):
     sel = ~edge
     print(f"    shader clock while resident: p50 {np.percentile(ghz, 50):.2f} GHz (p10 {np.percentile(ghz, 10):.2f}, p90 {np.percentile(ghz, 90):.2f}); "
           f"interior workgroups: {np.percentile(cyc[sel] / rows[sel], 50):.0f} cycles per lattice row of 128 px (p90 {np.percentile(cyc[sel] / rows[sel], 90):.0f})")
+    # placement: is a workgroup's "layer" on its CU (how many workgroups with a smaller id share the CU) the dispatch order
+    # within its XCD?  (pid = xcd + 8 k: the k-th workgroup of that XCD)
+    pid = np.nonzero(rec[:, 0] > 0)[0]
+    kk = pid >> 3
+    layer = np.zeros(len(pid), np.int64)
+    for key in np.unique(cu_key):
+        idx = np.nonzero(cu_key == key)[0]
+        layer[idx[np.argsort(pid[idx])]] = np.arange(len(idx))
+    print("    placement: k = pid >> 3 of the workgroups that are the 1st / 2nd / 3rd on their CU: " + "  ".join(
+        f"layer {q}: n {np.sum(layer == q)} k p5 {np.percentile(kk[layer == q], 5):.0f} p50 {np.percentile(kk[layer == q], 50):.0f} p95 {np.percentile(kk[layer == q], 95):.0f}"
+        for q in range(int(layer.max()) + 1)) + f";  XCC_ID == pid & 7 for {np.mean(xcc == (pid & 7)) * 100:.0f} % of them")
     occ = (dur.sum() / max(end.max(), 1)) / (len(per_cu) * (1 if p.atrous_variant == 7 else 3))
     print(f"    average resident workgroups / (CUs x slots per CU): {occ:.3f}")
