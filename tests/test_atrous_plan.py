@@ -125,7 +125,7 @@ def test_the_layered_order_of_a_small_frame(rmd):
     """1920x1080 on 256 CUs: 15 strips cut into 45 bands of 24 rows are 675 workgroups for 768 slots (a CU runs two or three of
     them: 3 x (24 + 4) staged rows decide the launch); layered, 15 tall bands (24) + 36 short ones (20) per strip are 765
     workgroups and every CU's three are one tall and two short ones.  (Measured: the launch alone 41.0 -> 39.0 us, the frame
-    loop 0.280 -> 0.293 ms -- the classic order keeps an XCD on the rows it wrote in the iteration before; DESIGN.md 4.8.)
+    loop 0.280 -> 0.293 ms -- the classic order keeps an XCD on the rows it wrote in the iteration before; DESIGN.md 4.6.)
     4K keeps the classic order either way: its rounds are full."""
     p = plan(rmd, 1920, 1080, 0, 1080, 0, layered=True)
     assert (p["lay_nb"], p["lay_ns"], p["lay_hb"], p["lay_hs"]) == (15, 36, 24, 20) and p["nblocks"] == 765
