@@ -72,7 +72,7 @@ struct AtrousArgs {
     // LAYERED order (one-round launches of small frames and strips, plan_stream): bands of two heights, the lay_nb tall ones
     // (lay_hb rows) first in the frame AND first in the workgroup order, then lay_ns short ones (lay_hs); workgroup id =
     // blockIdx.x, no XCD remap.  lay_nb + lay_ns = 0: the classic order above.  MEASURED AND LOST inside a frame (DESIGN.md
-    // section 4.8): off unless lay_force (rmd_debug_atrous_plan_layers) or RMD_ATROUS_LAYERED=1 in the experiments build.
+    // section 4.6): off unless lay_force (rmd_debug_atrous_plan_layers) or RMD_ATROUS_LAYERED=1 in the experiments build.
     int lay_nb, lay_ns, lay_hb, lay_hs, lay_force;
     int cus;       // CUs the launch may count on (rmd_svgf_params.atrous_cus or the whole device)
     int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
