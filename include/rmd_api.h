@@ -217,13 +217,6 @@ int rmd_debug_atrous_protocol_errors(unsigned int* count);
  * n/2 and the last n - n/2), workgroups of those strips (they come first in the order), workgroup slots per XCD.
  * Workgroup L (< out[0]): lattice L % step; strip group and band as in atrous_stream_kernel.  For tests.          */
 int rmd_debug_atrous_plan(int width, int height, int row0, int row1, int iteration, int cus, int* out);
-/* The same launch in the LAYERED order (bands of two heights, the tall ones first in the frame and in the workgroup order, so
- * that every CU runs one tall and two short workgroups; measured and lost inside a frame, DESIGN.md section 4.6: the library
- * only uses it with RMD_ATROUS_LAYERED=1 in the experiments build): out[5] = tall bands, short bands (per column = strip x
- * lattice), tall height, short height in rows, workgroups; all 0 where the planner would keep the classic order anyway.
- * Workgroup g < columns * tall: column g % columns, tall band g / columns; the others likewise among the short bands, which
- * follow the tall ones in the frame.  For tests.                                                                     */
-int rmd_debug_atrous_plan_layers(int width, int height, int row0, int row1, int iteration, int cus, int* out);
 /* T + V + `iterations` x A for final output rows [row0,row1).  Earlier passes are computed on
  * the rows later passes tap (redundant rows instead of per-pass halo exchanges);
  * those rows are clamped to the global frame and must lie inside the buffer. */

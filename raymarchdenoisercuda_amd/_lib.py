@@ -98,7 +98,6 @@ SYMBOLS = {
     "rmd_svgf_atrous2": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rmd_debug_atrous_protocol_errors": (C.c_int, [C.POINTER(C.c_uint)]),
     "rmd_debug_atrous_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
-    "rmd_debug_atrous_plan_layers": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rmd_svgf_frame": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
     "rmd_svgf_frame_tv": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P]),
     "rmd_svgf_frame_atrous": (C.c_int, [C.POINTER(SvgfFrameDesc), C.POINTER(SvgfParams), C.c_int, C.c_int, _P, _P]),

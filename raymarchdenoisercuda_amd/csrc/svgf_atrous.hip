@@ -69,11 +69,6 @@ struct AtrousArgs {
     // a SECOND row range in the same launch (stream kernel; the two boundary bands of a strip's exchanged iteration, which would
     // otherwise be two launches of one step each): its own band plan, workgroups nblocks .. nblocks + b_nblocks - 1
     int b_row0, b_row1, b_band_h, b_band_base, b_nblocks, b_n_hi, b_band_h_hi, b_nblocks_hi;
-    // LAYERED order (one-round launches of small frames and strips, plan_stream): bands of two heights, the lay_nb tall ones
-    // (lay_hb rows) first in the frame AND first in the workgroup order, then lay_ns short ones (lay_hs); workgroup id =
-    // blockIdx.x, no XCD remap.  lay_nb + lay_ns = 0: the classic order above.  MEASURED AND LOST inside a frame (DESIGN.md
-    // section 4.6): off unless lay_force (rmd_debug_atrous_plan_layers) or RMD_ATROUS_LAYERED=1 in the experiments build.
-    int lay_nb, lay_ns, lay_hb, lay_hs, lay_force;
     int cus;       // CUs the launch may count on (rmd_svgf_params.atrous_cus or the whole device)
     int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
 #ifdef RMD_EXPERIMENTS
@@ -824,50 +819,30 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(A
     // XCD-aware remap: workgroups pid, pid+8, ... share an XCD (round-robin dispatch), give each
     // XCD one contiguous run of logical work so halo columns / variance rows are shared in its L2.
     const int pid = blockIdx.x;
-    int L, r, x0, yb, bh, p_row0, p_row1;
-    if (a.lay_nb + a.lay_ns > 0) {
-        // Layered order.  The dispatcher deals workgroups pid, pid + 8, ... of an XCD out to its 32 CUs breadth first
-        // (tools/atrous_trace.py: the k-th workgroup of an XCD is the (k / 32 + 1)-th on its CU, without exception), so the
-        // first 256 workgroups of a launch sit one on each CU: the tall bands go there, and a CU's three workgroups are
-        // one tall and two short ones instead of three of one size fitted to fewer than 768 slots.
-        const int cols = a.nstrips * S, nbig = cols * a.lay_nb;
-        if (pid >= cols * (a.lay_nb + a.lay_ns)) return;
-        L = pid;
-        const bool tall = pid < nbig;
-        const int q = tall ? pid : pid - nbig;
-        const int col = q % cols, band = q / cols;
-        bh = tall ? a.lay_hb : a.lay_hs;
-        yb = a.band_base + (tall ? band * a.lay_hb : a.lay_nb * a.lay_hb + band * a.lay_hs);
-        r = col % S; x0 = (col / S) * C::CW;
-        p_row0 = a.row0; p_row1 = a.row1;
+    int L = (pid & (kXcds - 1)) * a.per_xcd + (pid >> 3);
+    if (L >= a.nblocks + a.b_nblocks) return;
+    // the launch's second row range, if any, follows the first in the workgroup order (scalar selects: L is wave-uniform)
+    const bool second = L >= a.nblocks;
+    if (second) L -= a.nblocks;
+    const int p_row0 = second ? a.b_row0 : a.row0, p_row1 = second ? a.b_row1 : a.row1;
+    const int p_band_h = second ? a.b_band_h : a.band_h, p_band_base = second ? a.b_band_base : a.band_base;
+    const int p_n_hi = second ? a.b_n_hi : a.n_hi, p_band_h_hi = second ? a.b_band_h_hi : a.band_h_hi;
+    const int p_nblocks_hi = second ? a.b_nblocks_hi : a.nblocks_hi;
+    // Two groups of strips: n_hi strips (the outermost ones: their frame-edge body is the slower one) are cut into
+    // one band more than the others, so that the workgroup count lands on the resident slots (plan_stream).
+    int strip, band, bh;
+    const int r = L % S;
+    if (L < p_nblocks_hi) {
+        const int t = L / S, e = t % p_n_hi;
+        strip = e < p_n_hi / 2 ? e : a.nstrips - (p_n_hi - e); band = t / p_n_hi; bh = p_band_h_hi;
     } else {
-        // XCD-aware remap: workgroups pid, pid+8, ... share an XCD (round-robin dispatch), give each
-        // XCD one contiguous run of logical work so halo columns / variance rows are shared in its L2.
-        L = (pid & (kXcds - 1)) * a.per_xcd + (pid >> 3);
-        if (L >= a.nblocks + a.b_nblocks) return;
-        // the launch's second row range, if any, follows the first in the workgroup order (scalar selects: L is wave-uniform)
-        const bool second = L >= a.nblocks;
-        if (second) L -= a.nblocks;
-        p_row0 = second ? a.b_row0 : a.row0; p_row1 = second ? a.b_row1 : a.row1;
-        const int p_band_h = second ? a.b_band_h : a.band_h, p_band_base = second ? a.b_band_base : a.band_base;
-        const int p_n_hi = second ? a.b_n_hi : a.n_hi, p_band_h_hi = second ? a.b_band_h_hi : a.band_h_hi;
-        const int p_nblocks_hi = second ? a.b_nblocks_hi : a.nblocks_hi;
-        // Two groups of strips: n_hi strips (the outermost ones: their frame-edge body is the slower one) are cut into
-        // one band more than the others, so that the workgroup count lands on the resident slots (plan_stream).
-        int strip, band;
-        r = L % S;
-        if (L < p_nblocks_hi) {
-            const int t = L / S, e = t % p_n_hi;
-            strip = e < p_n_hi / 2 ? e : a.nstrips - (p_n_hi - e); band = t / p_n_hi; bh = p_band_h_hi;
-        } else {
-            const int t = (L - p_nblocks_hi) / S, n_lo = a.nstrips - p_n_hi;
-            strip = p_n_hi / 2 + t % n_lo; band = t / n_lo; bh = p_band_h;
-        }
-        x0 = strip * C::CW;
-        // bands start at band_base + k*bh; band_base is row0 rounded down to a multiple of 2S, which is
-        // all the (A,B) pairing needs (global lattice index floor(y/S) even at the top of a band)
-        yb = p_band_base + band * bh;
+        const int t = (L - p_nblocks_hi) / S, n_lo = a.nstrips - p_n_hi;
+        strip = p_n_hi / 2 + t % n_lo; band = t / n_lo; bh = p_band_h;
     }
+    const int x0 = strip * C::CW;
+    // bands start at band_base + k*bh; band_base is row0 rounded down to a multiple of 2S, which is
+    // all the (A,B) pairing needs (global lattice index floor(y/S) even at the top of a band)
+    const int yb = p_band_base + band * bh;
     const int lo = max(yb, p_row0), hi = min(yb + bh, p_row1);
     const int ybase = yb + r;
     const int jlo = lo > ybase ? (lo - ybase + S - 1) / S : 0;
@@ -977,33 +952,6 @@ static double plan_stream(AtrousArgs& a)
     a.nblocks_hi = best_x * S * nbands_hi;
     a.nblocks = a.nblocks_hi + (a.nstrips - best_x) * S * nbands;
     a.per_xcd = (a.nblocks + kXcds - 1) / kXcds;
-    // Layered candidate (launches the classic order runs in ONE round): n bands per column (strip x lattice), as many as
-    // the slots take, of heights hs and hs + unit.  Every CU then runs one workgroup of each layer of the order (see the
-    // kernel), the tall ones first, so its time is the sum of its workgroups' band heights (+ 4 staged halo rows each);
-    // compared with the same sum for the classic order, whose workgroups are all of one height and whose count (bands x
-    // columns) rarely lands on the slots.  A CU with two workgroups runs at 0.85 of the rate of one with three (§4.4).
-    a.lay_nb = a.lay_ns = a.lay_hb = a.lay_hs = 0;
-    static const int layered_env = tuning_env("RMD_ATROUS_LAYERED", 0);
-    const bool layered = layered_env != 0 || a.lay_force != 0;
-    const int n = slots / per_band;
-    auto cu_time = [&](const double staged_rows, const int resident) { return resident >= 3 ? staged_rows : resident == 2 ? staged_rows / 0.85 : staged_rows / 0.6; };
-    if (layered && a.b_row1 <= a.b_row0 && n >= 3 && C::WG_PER_CU == 3 && a.nblocks <= slots) {
-        const int c = (a.nblocks + a.cus - 1) / a.cus;                                      // workgroups on the fullest CU
-        const double classic = cu_time(c * (best_h / (double)S + 4.0), c);
-        const int hs = rows / n / unit * unit;
-        if (hs >= unit) {
-            const int nb = min(n, max(0, (rows - n * hs + unit - 1) / unit)), hb = hs + unit;
-            const int wgs = per_band * n, nbig = per_band * nb;
-            const int layers = (wgs + a.cus - 1) / a.cus;
-            double load = 0.0;
-            for (int l = 0; l < layers; ++l) load += (nbig > l * a.cus ? hb : hs) / (double)S + 4.0;
-            if (cu_time(load, layers) < 0.98 * classic) {      // (the classic order keeps neighbouring strips in one XCD's L2: it wins ties)
-                a.lay_nb = nb; a.lay_ns = n - nb; a.lay_hb = hb; a.lay_hs = hs;
-                a.nblocks = wgs;
-                a.per_xcd = (wgs + kXcds - 1) / kXcds;
-            }
-        }
-    }
     return best;
 }
 
@@ -1087,7 +1035,6 @@ extern "C" int rmd_debug_atrous_plan(int width, int height, int row0, int row1, 
     a.row0 = row0; a.row1 = row1; a.step = 1 << iteration; a.cus = cus;
     a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
     a.b_row0 = a.b_row1 = a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
-    a.lay_nb = a.lay_ns = a.lay_hb = a.lay_hs = a.lay_force = 0;
 #ifdef RMD_EXPERIMENTS
     a.side_units = 0;
 #endif
@@ -1100,32 +1047,6 @@ extern "C" int rmd_debug_atrous_plan(int width, int height, int row0, int row1, 
     }
     out[0] = a.nblocks; out[1] = a.nstrips; out[2] = a.band_base; out[3] = a.band_h; out[4] = a.band_h_hi;
     out[5] = a.n_hi; out[6] = a.nblocks_hi; out[7] = a.per_xcd;
-    return RMD_OK;
-}
-
-extern "C" int rmd_debug_atrous_plan_layers(int width, int height, int row0, int row1, int iteration, int cus, int* out)
-{
-    if (!out) return fail(RMD_E_NULL, "rmd_debug_atrous_plan_layers: out is NULL");
-    int plan[8];
-    if (int e = rmd_debug_atrous_plan(width, height, row0, row1, iteration, cus, plan)) return e;
-    AtrousArgs a;
-    a.g = Geom{ width, height, 0, height };
-    a.row0 = row0; a.row1 = row1; a.step = 1 << iteration; a.cus = cus;
-    a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
-    a.b_row0 = a.b_row1 = a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
-    a.lay_nb = a.lay_ns = a.lay_hb = a.lay_hs = 0;
-    a.lay_force = 1;
-#ifdef RMD_EXPERIMENTS
-    a.side_units = 0;
-#endif
-    switch (iteration) {
-        case 0: plan_stream<1, 2>(a); break;
-        case 1: plan_stream<2, 2>(a); break;
-        case 2: plan_stream<4, 2>(a); break;
-        case 3: plan_stream<8, 2>(a); break;
-        default: plan_stream<16, 2>(a); break;
-    }
-    out[0] = a.lay_nb; out[1] = a.lay_ns; out[2] = a.lay_hb; out[3] = a.lay_hs; out[4] = a.nblocks;
     return RMD_OK;
 }
 
@@ -1190,7 +1111,6 @@ int rmd::launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
     a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
     a.b_row0 = two ? row0b : 0; a.b_row1 = two ? row1b : 0;
     a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
-    a.lay_nb = a.lay_ns = a.lay_hb = a.lay_hs = a.lay_force = 0;
     a.nt_out = (double)(row1 - row0 + (two ? row1b - row0b : 0)) * f->width * 48.0 > 256.0e6 ? 1 : 0;
 #ifdef RMD_EXPERIMENTS
     a.side_units = 0; a.side_every = 1; a.side_counter = nullptr;

@@ -10,19 +10,11 @@ import pytest
 CW, ADV, SLOTS_PER_CU = 128, 4, 3          # StreamCfg<S, 2>: strip width, lattice rows per step, workgroups per CU
 
 
-def plan(rmd, width, height, row0, row1, iteration, cus=256, layered=False):
+def plan(rmd, width, height, row0, row1, iteration, cus=256):
     out = (C.c_int * 8)()
     assert rmd.lib.rmd_debug_atrous_plan(width, height, row0, row1, iteration, cus, out) == 0, rmd.last_error()
     keys = ("nblocks", "nstrips", "band_base", "band_h", "band_h_hi", "n_hi", "nblocks_hi", "per_xcd")
-    p = dict(zip(keys, out))
-    p.update(lay_nb=0, lay_ns=0, lay_hb=0, lay_hs=0)
-    if layered:              # the order the library keeps behind RMD_ATROUS_LAYERED (experiments build): same kernel decode
-        lay = (C.c_int * 5)()
-        assert rmd.lib.rmd_debug_atrous_plan_layers(width, height, row0, row1, iteration, cus, lay) == 0, rmd.last_error()
-        p.update(zip(("lay_nb", "lay_ns", "lay_hb", "lay_hs"), lay))
-        if lay[0] + lay[1] > 0:
-            p["nblocks"] = lay[4]
-    return p
+    return dict(zip(keys, out))
 
 
 def coverage(p, step, width, row0, row1):
@@ -30,21 +22,6 @@ def coverage(p, step, width, row0, row1):
     (row, strip) cell is produced (lattices are interleaved rows, so row index covers them)."""
     hits = np.zeros((row1, p["nstrips"]), np.int32)
     for L in range(p["nblocks"]):
-        if p["lay_nb"] + p["lay_ns"] > 0:                 # layered order: tall bands first, workgroup id = blockIdx.x
-            cols = p["nstrips"] * step
-            tall = L < cols * p["lay_nb"]
-            q = L if tall else L - cols * p["lay_nb"]
-            col, band = q % cols, q // cols
-            bh = p["lay_hb"] if tall else p["lay_hs"]
-            yb = p["band_base"] + (band * p["lay_hb"] if tall else p["lay_nb"] * p["lay_hb"] + band * p["lay_hs"])
-            r, strip = col % step, col // step
-            lo, hi = max(yb, row0), min(yb + bh, row1)
-            ybase = yb + r
-            jlo = (lo - ybase + step - 1) // step if lo > ybase else 0
-            jhi = (hi - ybase + step - 1) // step if hi > ybase else 0
-            for j in range(jlo, jhi):
-                hits[ybase + j * step, strip] += 1
-            continue
         r = L % step
         if L < p["nblocks_hi"]:
             t = L // step
@@ -70,21 +47,14 @@ def coverage(p, step, width, row0, row1):
     (7680, 4320, 2160 - 60, 2700 + 60),           # an interior rank's first a-trous launch of an 8-strip 8K run
     (7680, 4320, 0, 4320),
 ])
-@pytest.mark.parametrize("layered", [False, True])
-def test_every_row_is_produced_exactly_once(rmd, width, height, row0, row1, layered):
+def test_every_row_is_produced_exactly_once(rmd, width, height, row0, row1):
     for it in range(5):
         step = 1 << it
-        p = plan(rmd, width, height, row0, row1, it, layered=layered)
+        p = plan(rmd, width, height, row0, row1, it)
         assert p["nstrips"] == (width + CW - 1) // CW
         assert p["band_base"] % (2 * step) == 0 and p["band_base"] <= row0
         assert p["band_h"] % (step * ADV) == 0 and p["band_h_hi"] % (step * ADV) == 0
-        assert p["lay_hb"] % (step * ADV) == 0 and p["lay_hs"] % (step * ADV) == 0
-        if p["lay_nb"] + p["lay_ns"] > 0:
-            assert p["nblocks"] == p["nstrips"] * step * (p["lay_nb"] + p["lay_ns"]) <= SLOTS_PER_CU * 256
-            assert p["lay_hb"] == p["lay_hs"] + step * ADV and p["lay_hs"] > 0
-        assert 0 <= p["n_hi"] <= p["nstrips"]
-        if p["lay_nb"] + p["lay_ns"] == 0:
-            assert p["per_xcd"] * 8 >= p["nblocks"]
+        assert 0 <= p["n_hi"] <= p["nstrips"] and p["per_xcd"] * 8 >= p["nblocks"]
         hits = coverage(p, step, width, row0, row1)
         assert (hits[row0:row1] == 1).all(), f"iteration {it}: rows produced {np.unique(hits[row0:row1])} times"
         assert (hits[:row0] == 0).all()
@@ -119,19 +89,3 @@ def test_plan_arguments(rmd):
     for bad in ((0, 10, 0, 10, 0, 256), (10, 10, 5, 5, 0, 256), (10, 10, 0, 11, 0, 256), (10, 10, 0, 10, 5, 256), (10, 10, 0, 10, 0, 0)):
         assert rmd.lib.rmd_debug_atrous_plan(*bad, out) != 0
     assert rmd.lib.rmd_debug_atrous_plan(10, 10, 0, 10, 0, 256, None) != 0
-
-
-def test_the_layered_order_of_a_small_frame(rmd):
-    """1920x1080 on 256 CUs: 15 strips cut into 45 bands of 24 rows are 675 workgroups for 768 slots (a CU runs two or three of
-    them: 3 x (24 + 4) staged rows decide the launch); layered, 15 tall bands (24) + 36 short ones (20) per strip are 765
-    workgroups and every CU's three are one tall and two short ones.  (Measured: the launch alone 41.0 -> 39.0 us, the frame
-    loop 0.280 -> 0.293 ms -- the classic order keeps an XCD on the rows it wrote in the iteration before)
-    4K keeps the classic order either way: its rounds are full."""
-    p = plan(rmd, 1920, 1080, 0, 1080, 0, layered=True)
-    assert (p["lay_nb"], p["lay_ns"], p["lay_hb"], p["lay_hs"]) == (15, 36, 24, 20) and p["nblocks"] == 765
-    assert p["nstrips"] * p["lay_nb"] <= 256                      # the tall ones: at most one per CU
-    assert plan(rmd, 1920, 1080, 0, 1080, 0)["nblocks"] == 675    # the library's order
-    for it in range(5):
-        assert plan(rmd, 1920, 1080, 0, 1080, it, layered=True)["lay_nb"] > 0
-        q = plan(rmd, 3840, 2160, 0, 2160, it, layered=True)
-        assert q["lay_nb"] + q["lay_ns"] == 0
