@@ -370,6 +370,49 @@ TEST(SVGF_STRIPS)
     expect(differing == 0, "row strips reproduce the unsharded frame bit for bit");
 }
 
+// ---- two frames of an SvgfContext captured as a hipGraph (FrameGraph, rmd_graph_*) and replayed: the eager frames' bits --------
+TEST(FRAME_GRAPH)
+{
+    const int W = 320, H = 200;
+    const size_t n = (size_t)W * H;
+    SvgfParams p = svgfDefaultParams();
+    p.max_motion_rows = 8;
+    std::vector<CudaVector<float>> color, nd, motion;
+    for (int f = 0; f < 2; ++f) {
+        color.emplace_back(4 * n); nd.emplace_back(4 * n); motion.emplace_back(2 * n);
+        rmd_synth_desc d = { W, H, 0, H, 77u, f, 1.25f, -0.5f };
+        rmdCheck(rmd_synth_gbuffer(&d, color[f].data(), nd[f].data(), motion[f].data(), nullptr, nullptr), "synth");
+    }
+    void* stream = nullptr;
+    rmdCheck(rmd_stream_create(&stream), "stream");
+    auto pair = [&](SvgfContext& ctx, float* out) {       // frames 0, 1; frame 0's history is frame 1 of the pair before
+        ctx.denoise(p, color[0].data(), nd[0].data(), motion[0].data(), nd[1].data(), out, 0, H, stream);
+        ctx.denoise(p, color[1].data(), nd[1].data(), motion[1].data(), nd[0].data(), out, 0, H, stream);
+    };
+    CudaVector<float> want(4 * n), got(4 * n);
+    {
+        SvgfContext ctx(W, H);
+        for (int k = 0; k < 4; ++k) pair(ctx, want.data());
+        rmdCheck(rmd_stream_sync(stream), "sync");
+    }
+    {
+        SvgfContext ctx(W, H);
+        pair(ctx, got.data());                             // eager: kernel attributes set, history valid
+        rmdCheck(rmd_stream_sync(stream), "sync");
+        FrameGraph graph;
+        FrameGraph::begin(stream);
+        pair(ctx, got.data());                             // captured, not run
+        graph.end(stream);
+        for (int k = 0; k < 3; ++k) graph.launch(stream);
+        rmdCheck(rmd_stream_sync(stream), "sync");
+    }
+    CpuVector<float> a, b;
+    want.copyTo(a); got.copyTo(b);
+    expect(memcmp(&a[0], &b[0], 4 * n * sizeof(float)) == 0, "frames replayed from a graph equal the eager frames bit for bit");
+    expect(rmd_graph_capture_begin(nullptr) == RMD_E_NULL, "the NULL stream cannot be captured");
+    rmdCheck(rmd_stream_destroy(stream), "stream");
+}
+
 // ---- full SVGF at 4K on the synthetic scene (BASELINE config 3), timed with HIP events -------
 // The G-buffers of all frames are generated first and stay resident; the timed frames are issued
 // back to back on the default stream between ONE pair of events (a sync per frame would time the
