@@ -25,7 +25,7 @@ all: lib oracle host
 
 lib: $(LIB)
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/rmd_api.h Makefile $(wildcard $(CSRC)/*.inc)
+build/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) include/rmd_api.h Makefile $(wildcard $(CSRC)/*.inc) $(wildcard $(CSRC)/experiments/*.inc)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
