@@ -127,6 +127,110 @@ __global__ __launch_bounds__(256) void box_lds_kernel(const uchar4* __restrict__
     }
 }
 
+// ---- scan kernel: radii up to 32 at a cost that does not grow with the radius -----------------------------------------
+// box_lds_kernel above adds 2r+1 taps per row sum and 2r+1 row sums per pixel (r = 8 at 4K: ~250 VALU instructions and 51 LDS
+// reads per pixel, 100-110 us).  Here
+//   - a wave takes a staged row of 64 + 2r <= 128 pixels, two per lane, packs each pixel as (R | G << 16, B) and forms the
+//     row's PREFIX sums with a DPP scan over the lanes' pair sums (row_shr 1/2/4/8, row_bcast 15/31: six v_add_u32_dpp per
+//     word); a window's row sum is then prefix[x + 2r] - prefix[x - 1], two reads from the wave's LDS scratch row (fields
+//     stay below 2^16: 128 pixels of 255);
+//   - a thread walks down 8 output rows of its column with a RUNNING vertical sum: + the row sum that enters, - the one that
+//     leaves (32-bit per channel: a window sum reaches (2r+1)^2 * 255);
+//   - the quotient is floor((s + 1/2) / n) as one fma with v_rcp_f32(n): s and n are integers, so (s + 1/2) / n is at least
+//     1/(2n) >= 1.18e-4 away from every integer and the two roundings (rcp 1 ulp, fma 1/2 ulp of a value <= 255) move it by
+//     less than 5e-5; for integers floor((s + 1/2) / n) = floor(s / n), which is what the reference's
+//     (unsigned char)((float)s / (float)n) gives (box_stream_kernel's comment).
+// Same result as every other box kernel, bit for bit (tests/test_box_gpu.py: radii 5, 9, 24, 30 and the ragged shapes).
+constexpr int kScanMaxRadius = 32;       // 32 output rows per workgroup, 8 per wave (64 rows: 46.9 us instead of 40.1 at radius 8, 4K --
+                                         // 41 KB of LDS leave a CU three workgroups instead of six)
+
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+template <bool GRAY, int kScanRows>
+__global__ __launch_bounds__(256) void box_scan_kernel(const uchar4* __restrict__ in, uchar4* __restrict__ out, int W, int H, int radius)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char box_lds[];
+    const int tileW = kBoxBlockX + 2 * radius, tileH = kScanRows + 2 * radius;
+    uint2* hs = reinterpret_cast<uint2*>(box_lds);                      // [tileH][64] row sums of the 64 windows: (R | G << 16, B)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2* P = hs + tileH * kBoxBlockX + wave * (tileW + 1);            // this wave's prefix row: P[i] = pixels 0 .. i-1
+    const int x0 = blockIdx.x * kBoxBlockX, y0 = blockIdx.y * kScanRows;
+
+    // A lane takes pixels 2 lane and 2 lane + 1 of the staged row (64 + 2r <= 128 of them); the rows of a wave are fetched four
+    // at a time before any of them is scanned (a row at a time, the pass waited for one memory round trip per row).
+    const int tx = 2 * lane, gxa = x0 - radius + tx, gxb = gxa + 1;
+    const bool oka = tx < tileW && gxa >= 0 && gxa < W, okb = tx + 1 < tileW && gxb >= 0 && gxb < W;
+    const unsigned* in32 = reinterpret_cast<const unsigned*>(in);
+    for (int ty0 = wave; ty0 < tileH; ty0 += 16) {
+        unsigned ua[4], ub[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gy = y0 - radius + ty0 + 4 * k;
+            const bool rowok = ty0 + 4 * k < tileH && gy >= 0 && gy < H;
+            ua[k] = (rowok && oka) ? in32[(size_t)gy * W + gxa] : 0u;               // out-of-frame cells add nothing
+            ub[k] = (rowok && okb) ? in32[(size_t)gy * W + gxb] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ty = ty0 + 4 * k;
+            if (ty >= tileH) break;                                                  // wave-uniform
+            const unsigned a0 = (ua[k] & 0xffu) | ((ua[k] & 0xff00u) << 8), b0 = (ua[k] >> 16) & 0xffu;
+            const unsigned a1 = a0 + ((ub[k] & 0xffu) | ((ub[k] & 0xff00u) << 8)), b1 = b0 + ((ub[k] >> 16) & 0xffu);
+            const unsigned ea = wave_inclusive_scan(a1) - a1, eb = wave_inclusive_scan(b1) - b1;      // the lanes before this one
+            if (tx < tileW)     P[tx + 1] = make_uint2(ea + a0, eb + b0);
+            if (tx + 1 < tileW) P[tx + 2] = make_uint2(ea + a1, eb + b1);
+            if (lane == 0) P[0] = make_uint2(0u, 0u);
+            __builtin_amdgcn_wave_barrier();                            // (one wave's LDS accesses execute in order)
+            const uint2 hi = P[lane + 2 * radius + 1], lo = P[lane];
+            hs[ty * kBoxBlockX + lane] = make_uint2(hi.x - lo.x, hi.y - lo.y);
+            __builtin_amdgcn_wave_barrier();                            // before the next row overwrites P
+        }
+    }
+    __syncthreads();
+
+    const int gx = x0 + lane;
+    if (gx >= W) return;
+    const int cntx = min(gx + radius, W - 1) - max(gx - radius, 0) + 1;
+    const int oy0 = wave * (kScanRows / 4);
+    unsigned sr = 0u, sg = 0u, sb = 0u;
+    for (int k = 0; k <= 2 * radius; ++k) {
+        const uint2 h = hs[(oy0 + k) * kBoxBlockX + lane];
+        sr += h.x & 0xffffu; sg += h.x >> 16; sb += h.y;
+    }
+    for (int i = 0; i < kScanRows / 4; ++i) {
+        const int oy = oy0 + i, gy = y0 + oy;
+        if (gy >= H) break;
+        const int cnty = min(gy + radius, H - 1) - max(gy - radius, 0) + 1;
+        const float inv = __builtin_amdgcn_rcpf((float)(cntx * cnty)), half = 0.5f * inv;
+        const unsigned qr = (unsigned)__builtin_fmaf((float)sr, inv, half);
+        uchar4 o;
+        if (GRAY) o = make_uchar4((unsigned char)qr, (unsigned char)qr, (unsigned char)qr, 0);
+        else o = make_uchar4((unsigned char)qr, (unsigned char)(unsigned)__builtin_fmaf((float)sg, inv, half),
+                             (unsigned char)(unsigned)__builtin_fmaf((float)sb, inv, half), 0);
+        out[(size_t)gy * W + gx] = o;
+        if (i + 1 < kScanRows / 4) {
+            const uint2 hn = hs[(oy + 2 * radius + 1) * kBoxBlockX + lane], ho = hs[oy * kBoxBlockX + lane];
+            sr += (hn.x & 0xffffu) - (ho.x & 0xffffu); sg += (hn.x >> 16) - (ho.x >> 16); sb += hn.y - ho.y;
+        }
+    }
+}
+
+static int box_scan_rows(int) { return 32; }
+static size_t box_scan_lds_bytes(int radius)
+{
+    const size_t tileW = kBoxBlockX + 2 * radius, tileH = box_scan_rows(radius) + 2 * radius;
+    return (tileH * kBoxBlockX + 4 * (tileW + 1)) * sizeof(uint2);
+}
+
 // ---- stream kernel: the fast path for radius 1..4 (the reference runs radius 2) ---------------
 // No LDS, no barriers.  A wave owns a 256-pixel column strip of one band of rows (a lane = 4
 // consecutive pixels = one 16-byte load, 1 KB per wave and row) and walks down it:
@@ -352,8 +456,15 @@ static int run_levels(const rmd_gbuffer& f, const rmd_filter_params& p, bool use
     for (int level = 0; level < p.depth; ++level) {
         const uchar4* in = reinterpret_cast<const uchar4*>(level == 0 ? f.render : f.buffer[level % 2]);
         uchar4* out = reinterpret_cast<uchar4*>(level == p.depth - 1 ? f.denoised : f.buffer[(level + 1) % 2]);
+        static const bool scan_off = tuning_env("RMD_BOX_SCAN", 1) == 0;         // A/B knob (experiments build)
         if (launch_box_stream<GRAY>(in, out, W, H, p.radius, stream)) {
             // radius 1..4 on 16-byte aligned planes of a width that is a multiple of 4: the stream kernel
+        } else if (!scan_off && p.radius >= 1 && p.radius <= kScanMaxRadius) {
+            // every other radius up to 32, whatever cacheInput says (the result does not depend on it): prefix sums + running sums
+            const int rows = box_scan_rows(p.radius);
+            dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + rows - 1) / rows);
+            if (rows == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(box_scan_kernel<GRAY, 64>), grid, dim3(256), box_scan_lds_bytes(p.radius), stream, in, out, W, H, p.radius);
+            else            hipLaunchKernelGGL(HIP_KERNEL_NAME(box_scan_kernel<GRAY, 32>), grid, dim3(256), box_scan_lds_bytes(p.radius), stream, in, out, W, H, p.radius);
         } else if (use_lds) {
             dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + kTileY - 1) / kTileY);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(box_lds_kernel<GRAY>), grid, dim3(256), box_lds_bytes(p.radius), stream,

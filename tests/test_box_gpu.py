@@ -61,6 +61,20 @@ def test_stream_kernel_radii_and_ragged_strips(rmd, orc, cuda, shape, r):
         assert (got == want).all(), (shape, r, tiled, np.argwhere(got != want)[:4])
 
 
+@pytest.mark.parametrize("r", [1, 5, 8, 16, 31, 32, 33])
+@pytest.mark.parametrize("shape", [(70, 61), (100, 200), (33, 130)])
+def test_scan_kernel_radii(rmd, orc, cuda, shape, r):
+    """Radii 1..32 outside the stream kernel's reach (here: widths that are not multiples of 4, or radius > 4) run prefix sums
+    along the rows and running sums down the columns; 33 falls back to the LDS / direct kernels.  A saturated frame makes
+    the largest sums the packed 16-bit prefix fields and the reciprocal division have to carry; bit-exact either way."""
+    rng = np.random.default_rng(7 * r + shape[1])
+    for img in (rng.integers(0, 256, shape + (4,), dtype=np.uint8), np.full(shape + (4,), 255, np.uint8)):
+        for tiled, cache in ((True, True), (True, False), (False, True)):
+            got = run_gpu(rmd, img, r, 1, tiled, cache)
+            want = orc.box_filter(img, r, 1, gray_from_r=not tiled)
+            assert (got == want).all(), (shape, r, tiled, cache, np.argwhere(got != want)[:4])
+
+
 @pytest.mark.parametrize("tiled", [False, True])
 def test_multi_level_ping_pong(rmd, orc, cuda, tiled):
     """depth>1 with the reference's plane routing (src/filter.cu:24-25), one launch per level."""

@@ -17,7 +17,10 @@ frame = rmd.make_gbuffer(planes["render"], out, bufs[0], bufs[1], normal=planes[
 cases = [("baseline AVERAGE r=2 depth=1", rmd.filterKernelBaseline, rmd.FilterParams(radius=2, depth=1)),
          ("tiled    AVERAGE r=2 depth=1", rmd.filterKernelTiled, rmd.FilterParams(radius=2, depth=1)),
          ("tiled    AVERAGE r=2 depth=5", rmd.filterKernelTiled, rmd.FilterParams(radius=2, depth=5)),
+         ("tiled    AVERAGE r=5 depth=1", rmd.filterKernelTiled, rmd.FilterParams(radius=5, depth=1)),
          ("tiled    AVERAGE r=8 depth=1", rmd.filterKernelTiled, rmd.FilterParams(radius=8, depth=1)),
+         ("tiled    AVERAGE r=16 depth=1", rmd.filterKernelTiled, rmd.FilterParams(radius=16, depth=1)),
+         ("tiled    AVERAGE r=32 depth=1", rmd.filterKernelTiled, rmd.FilterParams(radius=32, depth=1)),
          ("tiled    GAUSSIAN r=2", rmd.filterKernelTiled, rmd.FilterParams(type=rmd.FilterParams.GAUSSIAN, radius=2, sigmaSpace=1.5)),
          ("tiled    CROSS r=2", rmd.filterKernelTiled, rmd.FilterParams(type=rmd.FilterParams.CROSS, radius=2, sigmaSpace=1.5, sigmaColor=0.2, sigmaNormal=0.2, sigmaAlbedo=0.2)),
          ("tiled    WAVELET depth=5", rmd.filterKernelTiled, rmd.FilterParams(type=rmd.FilterParams.WAVELET, depth=5, sigmaColor=0.2, sigmaNormal=0.2, sigmaAlbedo=0.2))]
