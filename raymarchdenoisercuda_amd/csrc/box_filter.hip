@@ -8,11 +8,13 @@
 //   - workgroup = 256 threads = 4 wave64s; a wave owns 64 consecutive x, so each row access of a
 //     wave is one 256-byte coalesced uchar4 segment.
 //   - direct kernel: float accumulation in the reference's tap order (dx outer, dy inner).
-//   - LDS kernel (cacheInput=true, the job of reference cacheTile src/filter.cu:60-85): a
-//     64x16 output tile + halo is staged once in LDS with ONE consistent stride (the reference
-//     stages with a rounded stride and reads with the unrounded one), then the box
-//     sum is done separably on integers: all partial sums are < 2^24, so integer sums converted
-//     to float equal the reference's float accumulation exactly, for any order.
+//   - stream kernel (radius 1..4, the reference's radius 2): no LDS, DPP neighbours, a register ring of row sums.
+//   - scan kernel (every other radius up to 32; the job of reference cacheTile src/filter.cu:60-85: tile + halo
+//     staged once per workgroup): prefix sums along the staged rows, running sums down the columns; the staged form
+//     is the rows' window sums in LDS with ONE consistent stride (the reference stages with a rounded stride and
+//     reads with the unrounded one).  The sums are integers < 2^24, so they equal the reference's float
+//     accumulation exactly, for any order.
+//   - LDS kernel (experiments build; what the scan kernel replaced): 64x16 tile + halo in LDS, 2r+1 taps per sum.
 //   - one launch per level: the reference's in-kernel level loop has only __syncthreads()
 //     between levels although taps cross blocks (src/filter.cu:56,156) — an inter-block race.
 #include "common.h"
@@ -56,6 +58,7 @@ __global__ __launch_bounds__(256) void box_direct_kernel(const uchar4* __restric
     out[(size_t)y * W + x] = o;
 }
 
+#ifdef RMD_EXPERIMENTS
 // ---- LDS kernel: tile + halo staged once, separable integer box sum -------------------------
 // dynamic LDS: uchar4 tile[(kTileY+2r)][64+2r] followed by uint2 hsum[(kTileY+2r)][64]
 // (hsum.x = R | G<<16, hsum.y = B; each row sum <= 255*(2r+1) <= 65025 fits 16 bits)
@@ -126,9 +129,10 @@ __global__ __launch_bounds__(256) void box_lds_kernel(const uchar4* __restrict__
         out[(size_t)gy * W + gx] = o;
     }
 }
+#endif
 
 // ---- scan kernel: radii up to 32 at a cost that does not grow with the radius -----------------------------------------
-// box_lds_kernel above adds 2r+1 taps per row sum and 2r+1 row sums per pixel (r = 8 at 4K: ~250 VALU instructions and 51 LDS
+// box_lds_kernel (experiments build) adds 2r+1 taps per row sum and 2r+1 row sums per pixel (r = 8 at 4K: ~250 VALU instructions and 51 LDS
 // reads per pixel, 100-110 us).  Here
 //   - a wave takes a staged row of 64 + 2r <= 128 pixels, two per lane, packs each pixel as (R | G << 16, B) and forms the
 //     row's PREFIX sums with a DPP scan over the lanes' pair sums (row_shr 1/2/4/8, row_bcast 15/31: six v_add_u32_dpp per
@@ -465,10 +469,12 @@ static int run_levels(const rmd_gbuffer& f, const rmd_filter_params& p, bool use
             dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + rows - 1) / rows);
             if (rows == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(box_scan_kernel<GRAY, 64>), grid, dim3(256), box_scan_lds_bytes(p.radius), stream, in, out, W, H, p.radius);
             else            hipLaunchKernelGGL(HIP_KERNEL_NAME(box_scan_kernel<GRAY, 32>), grid, dim3(256), box_scan_lds_bytes(p.radius), stream, in, out, W, H, p.radius);
-        } else if (use_lds) {
+#ifdef RMD_EXPERIMENTS
+        } else if (use_lds) {               // (reached with RMD_BOX_SCAN=0 only: the scan kernel takes every radius this one can)
             dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + kTileY - 1) / kTileY);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(box_lds_kernel<GRAY>), grid, dim3(256), box_lds_bytes(p.radius), stream,
                                in, out, W, H, p.radius);
+#endif
         } else {
             dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + kBoxBlockY - 1) / kBoxBlockY);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(box_direct_kernel<GRAY>), grid, dim3(256), 0, stream, in, out, W, H, p.radius);

@@ -37,7 +37,7 @@ def test_cornell_known_answers(rmd, orc, cuda, size, kind, cache):
 @pytest.mark.parametrize("tiled,cache", [(False, True), (True, False), (True, True)])
 def test_edge_shapes(rmd, orc, cuda, shape, r, tiled, cache):
     """Empty-ish and ragged inputs: 1x1, radius 0, radius larger than the image, sizes that are not
-    multiples of the 64x16 tile, the largest LDS radius (24) and one beyond it (direct fallback)."""
+    multiples of a tile, radii the scan kernel takes (up to 32: 3, 5, 9, 24, 30 here) and radius 0 (direct kernel)."""
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
     got = run_gpu(rmd, img, r, 1, tiled, cache)
