@@ -114,6 +114,15 @@ struct CenterAux {          // per pixel, not packed (edge terms use abs/neg sou
     float iz[5];            // log2e/(za*len+1e-8) for len = 1, sqrt2, 2, sqrt5, 2*sqrt2
     bool zero;              // centre normal is (0,0,0)
 };
+
+// Appendix A.A.2 without a branch: both normals zero => w_n = 1, exactly one zero => 0.  With zc = 1 for a zero centre
+// normal (else 0) and ft = 1 for a zero tap normal (else 0), the cosine becomes clamp01(n_p.n_t + zc * ft): the dot product
+// itself (same bits) for zc = 0, where a zero tap gives 0 and log2(0) = -inf; 1 for two zero normals; 0 for a zero centre
+// and a non-zero tap.  ft costs v_max3_f32(|x|,|y|,|z|) + compare + select per tap, the rest stays packed.
+__device__ __forceinline__ float tap_is_zero(const float4 n)
+{
+    return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z)) == 0.0f ? 1.0f : 0.0f;
+}
 template <class T>
 struct Acc { T sw, sl, sr, sg, sv; };
 
@@ -196,10 +205,7 @@ template <bool ZERO_AWARE>
 __device__ __forceinline__ float tap_exponent(float cosine, float e0, float sigma_n, float zp, float lp, float il,
                                               const CenterAux& x, const Tap& t, bool tap_zero, int adx, int ady)
 {
-    float e = fma_(sigma_n, log2_(cosine), e0);
-    if (ZERO_AWARE) {   // Appendix A.A.2: both normals zero => w_n = 1, exactly one zero => 0
-        if (x.zero) e = tap_zero ? e0 : kNegInf;
-    }
+    float e = fma_(sigma_n, log2_(cosine), e0);      // (zero-aware callers pass the cosine of tap_is_zero's rule)
     if (adx | ady) e = fma_(-fabsf(zp - t.n.w), x.iz[len_class(adx, ady)], e);
     return fma_(-fabsf(lp - t.c.x), il, e);
 }
@@ -219,8 +225,16 @@ template <bool ZERO_AWARE>
 __device__ __forceinline__ void tap_single(Acc<float>& s, const Center<float>& k, const CenterAux& x, const Tap& t,
                                            float e0, int adx, int ady, float sigma_n)
 {
-    const float e = tap_exponent<ZERO_AWARE>(tap_cosine<float>(k, t), e0, sigma_n, k.z, k.lum, k.il, x, t,
-                                             ZERO_AWARE && is_zero3(t.n), adx, ady);
+    float cosine;
+    if (ZERO_AWARE) {
+        float d = k.nx * t.n.x;
+        d = fma_(k.ny, t.n.y, d);
+        d = fma_(k.nz, t.n.z, d);
+        cosine = clamp01(fma_(x.zero ? 1.0f : 0.0f, tap_is_zero(t.n), d));
+    } else {
+        cosine = tap_cosine<float>(k, t);
+    }
+    const float e = tap_exponent<ZERO_AWARE>(cosine, e0, sigma_n, k.z, k.lum, k.il, x, t, false, adx, ady);
     tap_accumulate<float>(s, exp2_(e), t);
 }
 
@@ -231,28 +245,28 @@ template <bool ZERO_AWARE>
 __device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const CenterAux& xa, const CenterAux& xb,
                                          const Tap& t, float e0A, float e0B, int adx, int adyA, int adyB, float sigma_n)
 {
-    const f2 c = tap_cosine<f2>(k, t);
-    if constexpr (!ZERO_AWARE) {
-        // Every VALU instruction of this loop costs a full issue slot, so what can be
-        // packed is: sigma_n*log2(cos) + log2 k for both pixels (the two log2 k ride in an SGPR pair; sigma_n
-        // is kept in a VGPR to leave the one scalar operand slot to them) and the two differences; only the
-        // |.|-scaled terms stay scalar (packed f32 has no abs modifier).  Same operations as tap_exponent,
-        // same bits.
-        f2 e = fma_(f2{ sigma_n, sigma_n }, log2_(c), f2{ e0A, e0B });
-        const f2 dz = k.z - f2{ t.n.w, t.n.w }, dl = k.lum - f2{ t.c.x, t.c.x };
-        if (adx | adyA) e.x = fma_(-fabsf(dz.x), xa.iz[len_class(adx, adyA)], e.x);
-        if (adx | adyB) e.y = fma_(-fabsf(dz.y), xb.iz[len_class(adx, adyB)], e.y);
-        e.x = fma_(-fabsf(dl.x), k.il.x, e.x);
-        e.y = fma_(-fabsf(dl.y), k.il.y, e.y);
-        tap_accumulate<f2>(s, exp2_(e), t);
+    f2 c;
+    if constexpr (ZERO_AWARE) {
+        f2 d = k.nx * f2{ t.n.x, t.n.x };
+        d = fma_(k.ny, f2{ t.n.y, t.n.y }, d);
+        d = fma_(k.nz, f2{ t.n.z, t.n.z }, d);
+        const float ft = tap_is_zero(t.n);
+        c = pk_fma_lo_clamp(f2{ xa.zero ? 1.0f : 0.0f, xb.zero ? 1.0f : 0.0f }, f2{ ft, ft }, d);
     } else {
-        const bool tz = is_zero3(t.n);
-        float ca = c.x, cb = c.y;
-        asm("" : "+v"(ca), "+v"(cb));
-        const float ea = tap_exponent<ZERO_AWARE>(ca, e0A, sigma_n, k.z.x, k.lum.x, k.il.x, xa, t, tz, adx, adyA);
-        const float eb = tap_exponent<ZERO_AWARE>(cb, e0B, sigma_n, k.z.y, k.lum.y, k.il.y, xb, t, tz, adx, adyB);
-        tap_accumulate<f2>(s, f2{ exp2_(ea), exp2_(eb) }, t);
+        c = tap_cosine<f2>(k, t);
     }
+    // Every VALU instruction of this loop costs a full issue slot, so what can be
+    // packed is: sigma_n*log2(cos) + log2 k for both pixels (the two log2 k ride in an SGPR pair; sigma_n
+    // is kept in a VGPR to leave the one scalar operand slot to them) and the two differences; only the
+    // |.|-scaled terms stay scalar (packed f32 has no abs modifier).  Same operations as tap_exponent,
+    // same bits.
+    f2 e = fma_(f2{ sigma_n, sigma_n }, log2_(c), f2{ e0A, e0B });
+    const f2 dz = k.z - f2{ t.n.w, t.n.w }, dl = k.lum - f2{ t.c.x, t.c.x };
+    if (adx | adyA) e.x = fma_(-fabsf(dz.x), xa.iz[len_class(adx, adyA)], e.x);
+    if (adx | adyB) e.y = fma_(-fabsf(dz.y), xb.iz[len_class(adx, adyB)], e.y);
+    e.x = fma_(-fabsf(dl.x), k.il.x, e.x);
+    e.y = fma_(-fabsf(dl.y), k.il.y, e.y);
+    tap_accumulate<f2>(s, exp2_(e), t);
 }
 
 // A.A.3.  c = the centre in (lum, r, g, var) form.
