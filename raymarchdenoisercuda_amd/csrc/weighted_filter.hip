@@ -138,7 +138,9 @@ typedef float wf2 __attribute__((ext_vector_type(2)));
 // tile's 64 columns + 2 S either side, taps at column offsets dx S.  Their regions (55 .. 74 KB) leave a CU two workgroups
 // instead of three: 183-188 us per 4K level against 152 at S = 1 and 212 for the gather kernel.  At S = 16 the region is as
 // wide again as the tile (98 KB, one workgroup per CU; D = 8 with 512 threads and 147 KB measured 270 us): that level and
-// the ones above stay on the gather kernel.
+// the ones above stay on the gather kernel.  (Columns on the lattice as well -- the tile as 64 x 8 pixels of one of S^2
+// sub-images, a 68-column region at every spacing -- was built and measured: 406 us at S = 2, 1115 us at S = 16; lanes that
+// load and store 4 bytes every 4 S bytes cost more than all the arithmetic.)
 template <bool HAS_A, bool HAS_N, bool WAVELET, int S, int D>
 __global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel(WeightedArgs a)
 {

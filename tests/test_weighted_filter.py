@@ -101,8 +101,9 @@ def test_ragged_shapes_and_missing_planes(rmd, orc, cuda, shape):
         assert_close_u8(gpu_run(rmd, img, p, nrm, alb), orc.weighted_filter(img, p, nrm, alb), exact=mode == "GAUSSIAN")
         p0 = make_params(rmd, getattr(rmd.FilterParams, mode), sigmaAlbedo=0.0, sigmaNormal=0.0)
         assert_close_u8(gpu_run(rmd, img, p0), orc.weighted_filter(img, p0), exact=mode == "GAUSSIAN")
-    pw = make_params(rmd, rmd.FilterParams.WAVELET, level=3, depth=3)        # spacings 8 and 16 (the lattice tiles, 512 threads at 16) and 32 (gather kernel)
-    assert_close_u8(gpu_run(rmd, img, pw, nrm, alb), orc.weighted_filter(img, pw, nrm, alb))
+    for level in (3, 5):     # spacings 8 (the lattice tile), 16, 32 and 32, 64, 128 (the gather kernel)
+        pw = make_params(rmd, rmd.FilterParams.WAVELET, level=level, depth=3)
+        assert_close_u8(gpu_run(rmd, img, pw, nrm, alb), orc.weighted_filter(img, pw, nrm, alb))
     for radius in (0, 1, 3, 7, 12):          # GAUSSIAN: every radius the separable kernel takes (1..4 unrolled, the rest at run time)
         pg = make_params(rmd, rmd.FilterParams.GAUSSIAN, radius=radius, sigmaSpace=0.8 + radius)
         assert_close_u8(gpu_run(rmd, img, pg), orc.weighted_filter(img, pg), exact=True)
