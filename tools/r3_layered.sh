@@ -1,4 +1,5 @@
 #!/bin/bash
+# NOTE: RMD_ATROUS_LAYERED existed in commit 0bc5408 only (the order was measured and taken out again).
 # GPU box: svgf parity tests with the product library, then the frame loop at 1080p / 720p / 1440p / 4K with the layered a-trous
 # order off and on (experiments build reads RMD_ATROUS_LAYERED), alternating in one call
 R=$(pwd); OUT=$R/gpurun_out/${1:-r3lay}; mkdir -p $OUT

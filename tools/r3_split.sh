@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: RMD_ATROUS_SPLIT belonged to a split-column work order that was measured and not committed; kept as
+# the recipe of profiles/r03_split_column_ab.txt.
 # GPU box: svgf parity tests with the product library, then the frame loop at several sizes and one rank's strip of the 8K frame
 # with the split-column a-trous order off and on (experiments build reads RMD_ATROUS_SPLIT), alternating in one call
 R=$(pwd); OUT=$R/gpurun_out/${1:-r3split}; mkdir -p $OUT
