@@ -592,6 +592,46 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         make_center(t, var_c, gz, a.sigma_z, a.sigma_l, (float)S, k, aux);
     };
 
+    // The same for both pixels of the pair at once, interior form (no border tests): the prefilter's nine terms, the depth
+    // differences and the six reciprocals' arguments as packed f32 on the (A, B) register pairs -- the operations of setup() /
+    // make_center() lane for lane, so the same bits -- 19 instructions fewer per step.
+    auto setup_pair = [&](const int rbA, const int rbB, const Tap& tA, const Tap& tB, Center<f2>& k, CenterAux& xA, CenterAux& xB) {
+        const int cA = rbA + 2 * S * 16, cB = rbB + 2 * S * 16;
+        const float* vuA = var_lds + ((2 * pr + 0) * 2 + 0) * C::VAR_ROW + col;
+        const float* vdA = var_lds + ((2 * pr + 0) * 2 + 1) * C::VAR_ROW + col;
+        const float* vuB = var_lds + ((2 * pr + 1) * 2 + 0) * C::VAR_ROW + col;
+        const float* vdB = var_lds + ((2 * pr + 1) * 2 + 1) * C::VAR_ROW + col;
+        // prefilter9(ul, l, dl, u, c, d, ur, r, dr)
+        f2 v = pair_of(vuA[0], vuB[0]) * f2{ 0.0625f, 0.0625f };
+        v = fma_(f2{ 0.125f, 0.125f }, pair_of(lds_f1(lds, cA - 16 + 12), lds_f1(lds, cB - 16 + 12)), v);
+        v = fma_(f2{ 0.0625f, 0.0625f }, pair_of(vdA[0], vdB[0]), v);
+        v = fma_(f2{ 0.125f, 0.125f }, pair_of(vuA[1], vuB[1]), v);
+        v = fma_(f2{ 0.25f, 0.25f }, pair_of(tA.c.w, tB.c.w), v);
+        v = fma_(f2{ 0.125f, 0.125f }, pair_of(vdA[1], vdB[1]), v);
+        v = fma_(f2{ 0.0625f, 0.0625f }, pair_of(vuA[2], vuB[2]), v);
+        v = fma_(f2{ 0.125f, 0.125f }, pair_of(lds_f1(lds, cA + 16 + 12), lds_f1(lds, cB + 16 + 12)), v);
+        v = fma_(f2{ 0.0625f, 0.0625f }, pair_of(vdA[2], vdB[2]), v);
+        const f2 z = pair_of(tA.n.w, tB.n.w);
+        const f2 dzr = pair_of(lds_f1(lds, C::PLANE_BYTES + cA + 16 + 12), lds_f1(lds, C::PLANE_BYTES + cB + 16 + 12)) - z;
+        const f2 dzd = pair_of(zd_cur[0], zd_cur[1]) - z;
+        const float gzA = fabsf(dzr.x) + fabsf(dzd.x), gzB = fabsf(dzr.y) + fabsf(dzd.y);
+        // make_center
+        k.nx = pair_of(tA.n.x, tB.n.x); k.ny = pair_of(tA.n.y, tB.n.y); k.nz = pair_of(tA.n.z, tB.n.z); k.z = z;
+        k.lum = pair_of(tA.c.x, tB.c.x);
+        xA.zero = is_zero3(tA.n); xB.zero = is_zero3(tB.n);
+        constexpr float kInvLog2e = 1.0f / kLog2e, kEps = 1e-8f / kLog2e;
+        const f2 sd = { __builtin_amdgcn_sqrtf(v.x > 0.0f ? v.x : 0.0f), __builtin_amdgcn_sqrtf(v.y > 0.0f ? v.y : 0.0f) };
+        const f2 ild = fma_(f2{ a.sigma_l * kInvLog2e, a.sigma_l * kInvLog2e }, sd, f2{ kEps, kEps });
+        k.il = f2{ fast_rcp(ild.x), fast_rcp(ild.y) };
+        const f2 za = f2{ a.sigma_z * fmaxf(gzA, 1e-8f), a.sigma_z * fmaxf(gzB, 1e-8f) } * f2{ (float)S, (float)S };
+        constexpr float kLen[5] = { 1.0f, 1.41421356237309504880f, 2.0f, 2.23606797749978969641f, 2.82842712474619009760f };
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const f2 den = fma_(za, f2{ kLen[c] * kInvLog2e, kLen[c] * kInvLog2e }, f2{ kEps, kEps });
+            xA.iz[c] = fast_rcp(den.x); xB.iz[c] = fast_rcp(den.y);
+        }
+    };
+
     // ---- one step: this thread's outputs are lattice rows jw (A) and jw+1 (B), jw = j + 2*pr
     auto compute = [&](const int j) {
         const int jw = j + 2 * pr;
@@ -614,9 +654,14 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         cB.c = lds_f4(lds, rb(3) + 2 * S * 16); cB.n = lds_f4(lds, C::PLANE_BYTES + rb(3) + 2 * S * 16);
         Center<float> kA, kB;
         CenterAux xA, xB;
-        setup(0, yA, rb(2), cA, kA, xA);
-        setup(1, yB, rb(3), cB, kB, xB);
-        const Center<f2> kAB = pack(kA, kB);
+        Center<f2> kAB;
+        if constexpr (EDGE) {
+            setup(0, yA, rb(2), cA, kA, xA);
+            setup(1, yB, rb(3), cB, kB, xB);
+            kAB = pack(kA, kB);
+        } else {
+            setup_pair(rb(2), rb(3), cA, cB, kAB, xA, xB);
+        }
         kA = Center<float>{ kAB.nx.x, kAB.ny.x, kAB.nz.x, kAB.z.x, kAB.lum.x, kAB.il.x };   // lanes, not copies
         kB = Center<float>{ kAB.nx.y, kAB.ny.y, kAB.nz.y, kAB.z.y, kAB.lum.y, kAB.il.y };
         Acc<f2> sAB = { f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 }, f2{ 0, 0 } };
