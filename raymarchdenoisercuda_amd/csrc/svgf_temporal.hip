@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void svgf_temporal_kernel(TemporalArgs a)
     temporal_tile(a, blockIdx.x, a.row0 / 4 + blockIdx.y);
 }
 
+#ifdef RMD_EXPERIMENTS
 // Tiles claimed from a device counter shared with the a-trous launches that carried the pass as a side job
 __global__ __launch_bounds__(256) void svgf_temporal_claim_kernel(TemporalArgs a, unsigned* counter, int units)
 {
@@ -143,6 +144,8 @@ __global__ __launch_bounds__(256) void svgf_temporal_claim_kernel(TemporalArgs a
         __syncthreads();                                  // everybody has read the slot (a pass without tile flags has no barrier of its own)
     }
 }
+
+#endif
 
 #ifdef RMD_EXPERIMENTS
 // A fixed, small number of workgroups (one per CU) that walk over the tiles: the form that runs
@@ -233,6 +236,7 @@ int rmd::launch_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
     return RMD_OK;
 }
 
+#ifdef RMD_EXPERIMENTS
 // What the a-trous launches did not get to (rmd_svgf_frame_atrous_next): every workgroup claims tiles from the same counter
 // until it runs out.  Nobody waits for anybody; a launch that finds the counter at `units` returns at once.
 int rmd::launch_temporal_claim(const AtrousSide& side, void* stream)
@@ -243,6 +247,7 @@ int rmd::launch_temporal_claim(const AtrousSide& side, void* stream)
     RMD_LAUNCH_CHECK("svgf_temporal_claim_kernel");
     return RMD_OK;
 }
+#endif
 
 // T + V of a whole frame in one launch (svgf_temporal_variance_kernel): T on rows [row0,row1), V on [v_row0,v_row1).
 int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, int v_row0, int v_row1, void* stream)
