@@ -124,31 +124,33 @@ __global__ __launch_bounds__(256) void weighted_filter_kernel(WeightedArgs a)
 // tap (dx, dy) is weighed for both at once with packed f32 arithmetic (v_pk_add / v_pk_mul / v_pk_fma): lane 0 of the packed
 // registers is A's window, lane 1 is B's.  The planes are converted to float once per staged pixel, and the LDS image is laid
 // out FOR the packed operands: entry [r][c] of a plane holds the values of region rows r and r + 4 side by side
-// ({rA, rB, gA, gB} and {bA, bB, |t_A|^2, |t_B|^2}), so that one ds_read_b128 lands both pixels' tap in an aligned register
-// pair (rows 4..7 of the 12-row region are stored twice: as the B half of entry r - 4 and the A half of entry r).
-// Squared distances are formed as |k|^2 + |t|^2 - 2 k.t: all terms are integers below 2^24, hence exactly the oracle's
-// value whatever the grouping.  Exponent and sums use the oracle's fused multiply-adds in its order (dx outer, dy inner;
-// colour, albedo, normal), so the only difference to the oracle stays v_exp_f32 against expf, as in weighted_filter_kernel.
-// Out-of-frame taps get weight 0, which adds exactly nothing.  LDS 17 KB per plane (52 KB with all three: 3 workgroups
-// per CU, the VGPR budget's 3 waves per SIMD); the next tap's reads are issued before the current tap is weighed.
+// ({rA, rB, gA, gB} and {bA, bB}), so that a ds_read_b128 + a ds_read_b64 land both pixels' tap in aligned register pairs
+// (rows 4..7 of the 12-row region are stored twice: as the B half of entry r - 4 and the A half of entry r).
+// Squared distances from packed differences: integers below 2^24, hence exactly the oracle's value.  (Staging |t|^2 beside
+// the blue pair and forming |k|^2 + |t|^2 - 2 k.t saves one instruction per plane and tap and costs a third more LDS bytes:
+// 153 us against 137 for CROSS at 4K -- the LDS pipe, not the VALU, is what the last step came from.)  Exponent and sums use
+// the oracle's fused multiply-adds in its order (dx outer, dy inner; colour, albedo, normal), so the only difference to the
+// oracle stays v_exp_f32 against expf, as in weighted_filter_kernel.  Out-of-frame taps get weight 0, which adds exactly
+// nothing.  LDS 13 KB per plane (39 KB with all three; the VGPR budget keeps three workgroups per CU); the next tap's reads
+// are issued before the current tap is weighed.
 typedef float wf2 __attribute__((ext_vector_type(2)));
 
 // Dilated WAVELET levels (spacing S = 2, 4, 8) are the same filter on the S row lattices y mod S: a workgroup takes 2 D
 // consecutive rows of ONE lattice (pairs j and j + D, D = 4), the region is those rows + 2 lattice rows either side and the
-// tile's 64 columns + 2 S either side, taps at column offsets dx S.  Their regions (55 .. 74 KB) leave a CU two workgroups
-// instead of three: 183-188 us per 4K level against 152 at S = 1 and 212 for the gather kernel.  At S = 16 the region is as
-// wide again as the tile (98 KB, one workgroup per CU; D = 8 with 512 threads and 147 KB measured 270 us): that level and
-// the ones above stay on the gather kernel.  (Columns on the lattice as well -- the tile as 64 x 8 pixels of one of S^2
+// tile's 64 columns + 2 S either side, taps at column offsets dx S.  Regions of 41 and 46 KB (S = 2, 4: three workgroups per CU,
+// 143-146 us per 4K level) and 55 KB (S = 8: two, 175 us) against 132 at S = 1 and 208 for the gather kernel.  At S = 16 the
+// region is as wide again as the tile (74 KB, two workgroups per CU: 222 us; D = 8 with 512 threads 270 us with the older
+// 32-byte entries): that level and the ones above stay on the gather kernel.  (Columns on the lattice as well -- the tile as 64 x 8 pixels of one of S^2
 // sub-images, a 68-column region at every spacing -- was built and measured: 406 us at S = 2, 1115 us at S = 16; lanes that
 // load and store 4 bytes every 4 S bytes cost more than all the arithmetic.)
 template <bool HAS_A, bool HAS_N, bool WAVELET, int S, int D>
-__global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel(WeightedArgs a)
+__global__ __launch_bounds__(64 * D, (S <= 4 ? 3 : 2)) void weighted_tile_kernel(WeightedArgs a)
 {
     constexpr int TW = 64, R = 2, RW = TW + 2 * R * S, NR = D + 2 * R, NP = 1 + (HAS_A ? 1 : 0) + (HAS_N ? 1 : 0);
     constexpr int FULL = RW / 64, REM = RW - 64 * FULL;                 // whole 64-column chunks of the region, and the rest (a power of two)
     extern __shared__ __attribute__((aligned(16))) float4 weighted_lds[];
     float4* const prg = weighted_lds;                                    // [NP][NR][RW]  { rA, rB, gA, gB }
-    float4* const pbt = weighted_lds + NP * NR * RW;                     // [NP][NR][RW]  { bA, bB, |t_A|^2, |t_B|^2 }
+    float2* const pb2 = reinterpret_cast<float2*>(weighted_lds + NP * NR * RW);      // [NP][NR][RW]  { bA, bB }
     auto at = [](const int p, const int r, const int c) { return (p * NR + r) * RW + c; };
     const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int group = blockIdx.y / S, lattice = blockIdx.y - group * S;
@@ -157,9 +159,8 @@ __global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel
     const float inv2s[3] = { a.inv2s_color, HAS_A ? a.inv2s_albedo : a.inv2s_normal, a.inv2s_normal };
     auto put = [&](const int p, const int r, const int c, const uchar4 u, const uchar4 v) {      // entry r: region rows r (A half) and r + D (B half)
         const wf2 rp = { (float)u.x, (float)v.x }, gp = { (float)u.y, (float)v.y }, bp = { (float)u.z, (float)v.z };
-        const wf2 tt = __builtin_elementwise_fma(bp, bp, __builtin_elementwise_fma(gp, gp, rp * rp));
         prg[at(p, r, c)] = make_float4(rp.x, rp.y, gp.x, gp.y);
-        pbt[at(p, r, c)] = make_float4(bp.x, bp.y, tt.x, tt.y);
+        pb2[at(p, r, c)] = make_float2(bp.x, bp.y);
     };
     auto row_of = [&](const int r) { return (size_t)min(max(y0 + (r - R) * S, 0), a.H - 1) * a.W; };        // region row r
     auto col_of = [&](const int c) { return min(max(x0 - R * S + c, 0), a.W - 1); };                        // region column c
@@ -188,17 +189,17 @@ __global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel
     if (x >= a.W || yA >= a.H) return;
     const bool inside = x0 - R * S >= 0 && x0 + TW + R * S <= a.W && y0 - R * S >= 0 && y0 + (2 * D - 1 + R) * S < a.H;     // no tap of the tile leaves the frame
     const int cx = lx + R * S;
-    struct Tap { float4 rg[NP], bt[NP]; };
+    struct Tap { float4 rg[NP]; float2 b[NP]; };
     auto fetch = [&](const int dx, const int dyi) {              // window offset (dx S, (dyi - 2) S) of both pixels: entry row wv + dyi
         Tap t;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) { t.rg[p] = prg[at(p, wv + dyi, cx + dx * S)]; t.bt[p] = pbt[at(p, wv + dyi, cx + dx * S)]; }
+        for (int p = 0; p < NP; ++p) { t.rg[p] = prg[at(p, wv + dyi, cx + dx * S)]; t.b[p] = pb2[at(p, wv + dyi, cx + dx * S)]; }
         return t;
     };
     const Tap ctr = fetch(0, 2);
-    wf2 kr[NP], kg[NP], kb[NP], kk[NP];
+    wf2 kr[NP], kg[NP], kb[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) { kr[p] = wf2{ ctr.rg[p].x, ctr.rg[p].y }; kg[p] = wf2{ ctr.rg[p].z, ctr.rg[p].w }; kb[p] = wf2{ ctr.bt[p].x, ctr.bt[p].y }; kk[p] = wf2{ ctr.bt[p].z, ctr.bt[p].w }; }
+    for (int p = 0; p < NP; ++p) { kr[p] = wf2{ ctr.rg[p].x, ctr.rg[p].y }; kg[p] = wf2{ ctr.rg[p].z, ctr.rg[p].w }; kb[p] = wf2{ ctr.b[p].x, ctr.b[p].y }; }
     wf2 sr = { 0, 0 }, sg = sr, sb = sr, sw = sr;
     auto window = [&](auto inside_c) {
         constexpr bool interior = decltype(inside_c)::value;
@@ -214,9 +215,8 @@ __global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel
             if (!WAVELET) { const float e0 = (float)(dx * dx + dy * dy) * a.inv2s_space; e = wf2{ e0, e0 }; }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
-                const wf2 tr = { cur.rg[p].x, cur.rg[p].y }, tg = { cur.rg[p].z, cur.rg[p].w }, tb = { cur.bt[p].x, cur.bt[p].y }, tt = { cur.bt[p].z, cur.bt[p].w };
-                const wf2 dot = __builtin_elementwise_fma(kb[p], tb, __builtin_elementwise_fma(kg[p], tg, kr[p] * tr));
-                const wf2 d2 = __builtin_elementwise_fma(dot, wf2{ -2.0f, -2.0f }, kk[p] + tt);
+                const wf2 dr = kr[p] - wf2{ cur.rg[p].x, cur.rg[p].y }, dg = kg[p] - wf2{ cur.rg[p].z, cur.rg[p].w }, db = kb[p] - wf2{ cur.b[p].x, cur.b[p].y };
+                const wf2 d2 = __builtin_elementwise_fma(db, db, __builtin_elementwise_fma(dg, dg, dr * dr));     // exact: integers < 2^24
                 e = __builtin_elementwise_fma(d2, wf2{ inv2s[p], inv2s[p] }, e);
             }
             const wf2 m = e * wf2{ -1.442695041f, -1.442695041f };            // __expf(-e) = v_exp_f32(-e * log2(e)): the same product
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64 * D, (S == 1 ? 3 : 2)) void weighted_tile_kernel
             }
             sr = __builtin_elementwise_fma(w, wf2{ cur.rg[0].x, cur.rg[0].y }, sr);
             sg = __builtin_elementwise_fma(w, wf2{ cur.rg[0].z, cur.rg[0].w }, sg);
-            sb = __builtin_elementwise_fma(w, wf2{ cur.bt[0].x, cur.bt[0].y }, sb);
+            sb = __builtin_elementwise_fma(w, wf2{ cur.b[0].x, cur.b[0].y }, sb);
             sw += w;
         }
     };
@@ -257,7 +257,7 @@ template <bool HAS_A, bool HAS_N, bool WAVELET, int S, int D>
 static int launch_weighted_tile_at(const WeightedArgs& a, hipStream_t stream)
 {
     constexpr int NP = 1 + (HAS_A ? 1 : 0) + (HAS_N ? 1 : 0), RW = 64 + 4 * S, NR = D + 4;
-    constexpr int lds_bytes = 2 * (int)sizeof(float4) * NP * NR * RW;
+    constexpr int lds_bytes = 24 * NP * NR * RW;
     static_assert(lds_bytes <= 160 * 1024, "region larger than a CU's LDS");
     const auto kernel = &weighted_tile_kernel<HAS_A, HAS_N, WAVELET, S, D>;
     if (first_use_on_device(reinterpret_cast<const void*>(kernel)))

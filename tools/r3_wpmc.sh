@@ -8,4 +8,4 @@ for PMC in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_W
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT -o pass$i -- python3 $R/tools/box_probe.py > $OUT/pass$i.log 2>&1 || { echo "pass $i failed"; tail -5 $OUT/pass$i.log; exit 1; }
 done
-cd $R; python3 tools/pmc_summary.py $OUT --all > $OUT/summary.txt; grep -A14 "weighted_tile_kernel<true, true, false>" $OUT/summary.txt
+cd $R; python3 tools/pmc_summary.py $OUT --all > $OUT/summary.txt; grep -A14 "weighted_tile_kernel<true, true, false, 1, 4>" $OUT/summary.txt
