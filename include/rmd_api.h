@@ -248,8 +248,9 @@ int rmd_svgf_frame_atrous_next(const rmd_svgf_frame_desc* f, const rmd_svgf_para
  *                        stream, ordered behind an event recorded here;
  *   RMD_ATROUS_INTERIOR  iteration X on the remaining rows of the strip: runs while the halo travels;
  *   RMD_ATROUS_TAIL      after the exchange has completed: iterations X+1 ... (whole launches, halo rows included)
- *   RMD_ATROUS_ALL       everything in order (= rmd_svgf_frame_atrous; complete only where no halo is needed: whole frames,
- *                        or exchange_iteration = -1).
+ *   RMD_ATROUS_ALL       everything in order (= rmd_svgf_frame_atrous).  Only where no halo is needed: whole frames, or
+ *                        exchange_iteration = -1; a strip with exchange_iteration >= 0 is refused (RMD_E_PARAM): the
+ *                        iteration behind the exchanged one would read halo rows nobody delivered.
  * Same kernels on other row ranges: bit-identical to the unsharded frame (tests/test_svgf_gpu.py, test_sharding_*). */
 enum { RMD_ATROUS_ALL = 0, RMD_ATROUS_HEAD = 1, RMD_ATROUS_INTERIOR = 2, RMD_ATROUS_TAIL = 3 };
 int rmd_svgf_frame_atrous_part(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream,
@@ -282,11 +283,37 @@ int  rmd_svgf_context_denoise(rmd_svgf_context* ctx, const rmd_svgf_params* p,
                               const float* prev_nd, float* out, int row0, int row1, void* stream);
 /* The same frame in the parts of rmd_svgf_frame_atrous_part: RMD_ATROUS_HEAD runs T + V + iterations 0..X-1 + the boundary
  * rows of X, RMD_ATROUS_INTERIOR / RMD_ATROUS_TAIL the rest; the history planes rotate with the TAIL part.  Between HEAD and
- * TAIL the caller exchanges the rows of rmd_svgf_context_mid_plane with rank +-1 (rmd_mid_exchange). */
+ * TAIL the caller exchanges the rows of rmd_svgf_context_mid_plane with rank +-1 (rmd_mid_exchange).  RMD_ATROUS_ALL is
+ * rmd_svgf_context_denoise (T + V + every iteration + the rotation). */
 int  rmd_svgf_context_denoise_part(rmd_svgf_context* ctx, const rmd_svgf_params* p,
                                    const float* color, const float* nd, const float* motion,
                                    const float* prev_nd, float* out, int row0, int row1, void* stream, int part);
 int  rmd_svgf_context_mid_plane(rmd_svgf_context* ctx, const rmd_svgf_params* p, float** plane);
+/* SVGF straight on the reference's frame descriptor (include/gbuffer.h:6-14; CudaGBuffer::openImages, :20-33, is the
+ * declared hook that fills it): ONE call per frame, uchar4 `render` / `albedo` / `normal` in, uchar4 `denoised` out, six kernel
+ * launches.  It computes exactly what this chain of eight calls computes, to the byte (tests/test_gbuffer_frame_gpu.py):
+ *     rmd_convert_u8_to_f32(render, color, n, 0, 0)        rmd_convert_u8_to_f32(albedo, alb, n, 0, 0)
+ *     rmd_convert_u8_to_f32(normal, nd, n, 1, -1)          rmd_demodulate(color, alb, color, n, albedo_eps)
+ *     rmd_svgf_context_denoise(ctx, p, color, nd, motion, previous nd, out, 0, height, stream)
+ *     rmd_convert_f32_to_u8(out, alb, denoised, n)
+ * but the 8-bit ends run INSIDE the frame's first and last launch: the T+V kernel reads the three uchar4 planes (12 B/px instead
+ * of 32 B/px of float planes), converts, renormalises and demodulates in registers and writes the float (normal, depth) plane
+ * once (the a-trous passes and the next frame's reprojection read it; the context owns two of them); the last a-trous launch
+ * multiplies by the albedo, quantises and stores bytes (4 B/px written instead of 16).  The chain's five conversion launches
+ * and their 144 B/px do not exist.
+ *   normal.xyz  world normal in [0,1] as the reference's fixtures hold it, renormalised to unit length; (0,0,0) = no surface
+ *   normal.w    linear depth in units of 1/255.  The reference's GBuffer has no depth plane and its Image(path, 4) loader
+ *               yields an opaque alpha (255): depth 1 everywhere, which is also all the saturated depth.png of the fixture says
+ *   motion      float2 per pixel (current -> previous, pixels) or NULL = static camera
+ *   albedo_eps  > 0: floor of the demodulation's denominator (black albedo)
+ * `ctx` must hold whole frames of frame.shape; rmd_svgf_params.exchange_iteration must be -1, var_radius 3 (the front end lives in
+ * the fused T+V launch; RMD_E_UNSUPPORTED otherwise: take the float planes).  frame.buffer[] is not used.  Frames of this
+ * call and of rmd_svgf_context_denoise may alternate on one context; the first frame after a switch starts a new history. */
+int  rmd_svgf_gbuffer_frame(rmd_gbuffer frame, rmd_svgf_context* ctx, const rmd_svgf_params* p, const float* motion,
+                            float albedo_eps, void* stream);
+/* Optional int4 plane (q0.x, q0.y, tap mask, h per pixel, whole buffer) that T of every following frame of this context
+ * fills: the bit-exact outputs, for tests.  NULL switches it off. */
+int  rmd_svgf_context_set_debug_plane(rmd_svgf_context* ctx, int* t_debug);
 /* The history planes the NEXT rmd_svgf_context_denoise call will read (for halo exchange). */
 int  rmd_svgf_context_history(rmd_svgf_context* ctx, float** hist_color, float** hist_moments);
 /* Fill a descriptor with the context's planes for the next frame (advanced use / tests). */

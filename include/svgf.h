@@ -3,6 +3,7 @@
 #ifndef RMD_SVGF_H
 #define RMD_SVGF_H
 
+#include "gbuffer.h"
 #include "utils.h"
 
 using SvgfParams = rmd_svgf_params;
@@ -38,9 +39,23 @@ public:
     {
         rmdCheck(rmd_svgf_context_denoise_part(ctx, &p, color, nd, motion, prevNd, out, row0, row1, stream, part), "SvgfContext::denoisePart");
     }
+    // One frame straight on the reference's frame descriptor (include/gbuffer.h:6-14): uchar4 render / albedo / normal in, uchar4
+    // denoised out, six launches; the 8-bit conversions, the demodulation by albedo and the modulation + quantisation run inside
+    // the frame's first and last launch (rmd_svgf_gbuffer_frame).  motion: float2 per pixel (current -> previous) or NULL = static.
+    void denoise(const GBuffer& frame, const SvgfParams& p, const float* motion = nullptr, float albedoEps = 1.0f / 255.0f, void* stream = nullptr)
+    {
+        rmdCheck(rmd_svgf_gbuffer_frame(toAbi(frame), ctx, &p, motion, albedoEps, stream), "SvgfContext::denoise(GBuffer)");
+    }
     float* midPlane(const SvgfParams& p) { float* q = nullptr; rmdCheck(rmd_svgf_context_mid_plane(ctx, &p, &q), "SvgfContext::midPlane"); return q; }
     rmd_svgf_context* get() { return ctx; }
 };
+
+// The reference's intended call shape for its README's goal: SVGF on a GBuffer (README.md:3-10; include/gbuffer.h:6-14).
+inline void svgfDenoise(const GBuffer& frame, SvgfContext& ctx, const SvgfParams& p, const float* motion = nullptr,
+                        float albedoEps = 1.0f / 255.0f, void* stream = nullptr)
+{
+    ctx.denoise(frame, p, motion, albedoEps, stream);
+}
 
 // hipGraph capture of whatever is queued on `stream` between begin() and end() (rmd_graph_* in rmd_api.h), for a host whose
 // own launch path is slow.  Capture an even number of SvgfContext frames (the history planes ping-pong) after at least one

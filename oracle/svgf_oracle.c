@@ -315,3 +315,21 @@ void orc_convert_f32_to_u8(const float* in, const float* albedo, uint8_t* out, s
         out[i * 4 + 3] = 255;
     }
 }
+
+/* The product's 8-bit front end (csrc/pixel_convert.h unit_from_u8) computes (float)b / 255.0f WITHOUT a division: q = v * RN(1/255),
+ * e = fma(-q, 255, v) (exact residual), result = fma(e, RN(1/255), q).  This restates that formula with C99 fmaf and counts the
+ * bytes for which it differs from the IEEE quotient the oracle (and the reference-style c/255) uses: must be 0
+ * (tests/test_gbuffer_frame.py).  Test infrastructure, like everything in this directory. */
+int orc_unit_from_u8_mismatches(void)
+{
+    const float r = 1.0f / 255.0f;
+    int bad = 0;
+    for (int b = 0; b < 256; ++b) {
+        const float v = (float)b;
+        const float q = v * r;
+        const float e = fmaf(-q, 255.0f, v);
+        if (fmaf(e, r, q) != v / 255.0f) ++bad;
+    }
+    return bad;
+}
+

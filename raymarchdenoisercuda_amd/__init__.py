@@ -11,12 +11,12 @@ from ._lib import (FilterParams, GBuffer, Int2, LIB_PATH, RmdError, SvgfFrameDes
                    check, last_error, lib)
 from .filter import box_filter, filterKernelBaseline, filterKernelTiled, make_gbuffer
 from . import sharding, svgf
-from .svgf import SvgfDenoiser, default_params
+from .svgf import GBufferDenoiser, SvgfDenoiser, default_params
 from .graph import Graph, capture
 
 __all__ = ["FilterParams", "GBuffer", "Int2", "LIB_PATH", "RmdError", "SvgfFrameDesc", "SvgfParams", "SynthDesc",
            "check", "last_error", "lib", "box_filter", "filterKernelBaseline", "filterKernelTiled", "make_gbuffer",
-           "sharding", "svgf", "SvgfDenoiser", "default_params", "Graph", "capture", "HAS_EXPERIMENTS", "ATROUS_VARIANTS"]
+           "sharding", "svgf", "GBufferDenoiser", "SvgfDenoiser", "default_params", "Graph", "capture", "HAS_EXPERIMENTS", "ATROUS_VARIANTS"]
 
 
 # a-trous formulations this build of librmd.so can run (include/rmd_api.h rmd_svgf_params.atrous_variant): the product

@@ -114,6 +114,8 @@ SYMBOLS = {
     "rmd_svgf_context_denoise": (C.c_int, [_P, C.POINTER(SvgfParams), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "rmd_svgf_context_denoise_part": (C.c_int, [_P, C.POINTER(SvgfParams), _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int]),
     "rmd_svgf_context_mid_plane": (C.c_int, [_P, C.POINTER(SvgfParams), C.POINTER(_P)]),
+    "rmd_svgf_gbuffer_frame": (C.c_int, [GBuffer, _P, C.POINTER(SvgfParams), _P, C.c_float, _P]),
+    "rmd_svgf_context_set_debug_plane": (C.c_int, [_P, _P]),
     "rmd_svgf_context_history": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "rmd_svgf_context_describe": (C.c_int, [_P, C.POINTER(SvgfFrameDesc)]),
     "rmd_strip_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

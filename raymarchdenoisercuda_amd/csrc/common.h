@@ -78,8 +78,13 @@ int launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int 
                     bool sparse_t_color);
 // T + V of a whole frame in one launch (no statistics, var_radius 3): a workgroup that finds short-history pixels in its tile
 // recomputes T on the tile's 3-pixel halo and runs V for them itself (svgf_temporal.hip)
-int launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, int v_row0, int v_row1, void* stream);
+// g8 != NULL: the 8-bit front end of rmd_svgf_gbuffer_frame (pixel_convert.h) -- inputs from the GBuffer's uchar4 planes, f->nd written
+struct GBuffer8;
+int launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, int v_row0, int v_row1, void* stream,
+                             const GBuffer8* g8 = nullptr);
 bool variance_reads_sparse_t_color(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, bool fused);
+// float4 illumination x uchar4 albedo -> uchar4 (convert_synth.hip; rmd_convert_f32_to_u8's arithmetic on the GBuffer's own albedo plane)
+int launch_modulate_to_u8(const float* in, const void* albedo8, void* out8, size_t pixels, void* stream);
 
 }  // namespace rmd
 

@@ -7,43 +7,36 @@
 // TU is built with -ffp-contract=off) so it reproduces oracle/synth_oracle.c bit for bit and all
 // ranks generate identical pixels with no transfers.
 #include "common.h"
+#include "pixel_convert.h"
 #include <cmath>
+#include <type_traits>
 
 namespace rmd {
 
 // ------------------------------------------------------------------------------ conversion
+// (the per-pixel arithmetic lives in pixel_convert.h: the fused 8-bit ends of rmd_svgf_gbuffer_frame call the same functions)
 __global__ __launch_bounds__(256) void u8_to_f32_kernel(const uchar4* __restrict__ in, float4* __restrict__ out, size_t n,
                                                         int renorm, float w_value)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uchar4 p = in[i];
-        float x = (float)p.x / 255.0f, y = (float)p.y / 255.0f, z = (float)p.z / 255.0f;
-        if (renorm) {
-            const float l2 = x * x + y * y + z * z;
-            if (l2 > 0.0f) { const float inv = 1.0f / sqrtf(l2); x *= inv; y *= inv; z *= inv; }
-        }
-        out[i] = make_float4(x, y, z, w_value < 0.0f ? (float)p.w / 255.0f : w_value);
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = float4_from_u8(in[i], renorm != 0, w_value);
 }
 
-__global__ __launch_bounds__(256) void f32_to_u8_kernel(const float4* __restrict__ in, const float4* __restrict__ albedo,
+// albedo as a float4 plane (rmd_convert_f32_to_u8) or as the uchar4 plane of the GBuffer (the unfused tail of
+// rmd_svgf_gbuffer_frame when the last iteration is also the history iteration)
+template <class AlbedoT>
+__global__ __launch_bounds__(256) void f32_to_u8_kernel(const float4* __restrict__ in, const AlbedoT* __restrict__ albedo,
                                                         uchar4* __restrict__ out, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float4 c = in[i];
-        if (albedo) { const float4 al = albedo[i]; c.x = c.x * al.x; c.y = c.y * al.y; c.z = c.z * al.z; }
-        float v[3] = { c.x * 255.0f + 0.5f, c.y * 255.0f + 0.5f, c.z * 255.0f + 0.5f };
-        unsigned char b[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float t = v[k];
-            if (!(t > 0.0f)) t = 0.0f;
-            if (t > 255.0f) t = 255.0f;
-            b[k] = (unsigned char)t;
+        float4 al = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (albedo) {
+            if constexpr (std::is_same<AlbedoT, uchar4>::value) al = float4_from_u8(albedo[i], false, 0.0f);
+            else al = albedo[i];
         }
-        out[i] = make_uchar4(b[0], b[1], b[2], 255);
+        out[i] = u8_from_float4(in[i], albedo != nullptr, al);
     }
 }
 
@@ -55,10 +48,8 @@ __global__ __launch_bounds__(256) void demodulate_kernel(const float4* radiance,
                                                          float4* out, size_t n, float eps)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const float4 c = radiance[i], al = albedo[i];
-        out[i] = make_float4(c.x / fmaxf(al.x, eps), c.y / fmaxf(al.y, eps), c.z / fmaxf(al.z, eps), c.w);
-    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = demodulated(radiance[i], albedo[i], eps);
 }
 
 // ------------------------------------------------------------------------------ synthetic scene
@@ -181,6 +172,18 @@ static int g_tab_w[16], g_tab_h[16];
 
 using namespace rmd;
 
+// float4 illumination x the GBuffer's uchar4 albedo -> uchar4 (rows of a plane; the tail of rmd_svgf_gbuffer_frame when its
+// last a-trous launch cannot store bytes itself)
+int rmd::launch_modulate_to_u8(const float* in, const void* albedo8, void* out8, size_t pixels, void* stream)
+{
+    if (pixels == 0) return RMD_OK;
+    const unsigned blocks = (unsigned)((pixels + 255) / 256 < 2048 ? (pixels + 255) / 256 : 2048);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(f32_to_u8_kernel<uchar4>), dim3(blocks), dim3(256), 0, as_stream(stream),
+                       (const float4*)in, (const uchar4*)albedo8, (uchar4*)out8, pixels);
+    RMD_LAUNCH_CHECK("f32_to_u8_kernel<uchar4>");
+    return RMD_OK;
+}
+
 extern "C" {
 
 int rmd_convert_u8_to_f32(const rmd_uchar4* in, float* out, size_t pixels, int renormalize_xyz, float w_value, void* stream)
@@ -201,7 +204,7 @@ int rmd_convert_f32_to_u8(const float* in, const float* albedo, rmd_uchar4* out,
     if (!aligned_to(in, 16) || !aligned_to(albedo, 16) || !aligned_to(out, 4)) return fail(RMD_E_ALIGN, "rmd_convert_f32_to_u8: misaligned plane");
     if (pixels == 0) return RMD_OK;
     const unsigned blocks = (unsigned)((pixels + 255) / 256 < 2048 ? (pixels + 255) / 256 : 2048);
-    hipLaunchKernelGGL(f32_to_u8_kernel, dim3(blocks), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(f32_to_u8_kernel<float4>), dim3(blocks), dim3(256), 0, as_stream(stream),
                        (const float4*)in, (const float4*)albedo, (uchar4*)out, pixels);
     RMD_LAUNCH_CHECK("f32_to_u8_kernel");
     return RMD_OK;

@@ -38,6 +38,7 @@
 //   - normals are unit length by contract, so max(0, n.n) is applied as a [0,1] clamp.
 #include "common.h"
 #include "svgf_tv.h"
+#include "pixel_convert.h"
 #include <type_traits>
 
 namespace rmd {
@@ -71,6 +72,10 @@ struct AtrousArgs {
     int b_row0, b_row1, b_band_h, b_band_base, b_nblocks, b_n_hi, b_band_h_hi, b_nblocks_hi;
     int cus;       // CUs the launch may count on (rmd_svgf_params.atrous_cus or the whole device)
     int nt_out;    // store the outputs non-temporally (launches whose planes overflow the 256 MB Infinity Cache)
+    // 8-bit back end (the LAST iteration of rmd_svgf_gbuffer_frame, the OUT8 instantiations): the result is multiplied by the
+    // GBuffer's albedo, quantised as rmd_convert_f32_to_u8 does (pixel_convert.h) and stored as uchar4 to `out8` -- 4 B/px
+    // written instead of 16, and no conversion launch behind the frame; `out` is not written.
+    const uchar4* albedo8; uchar4* out8;
 #ifdef RMD_EXPERIMENTS
     // SIDE JOB (stream kernel, rmd_svgf_frame_atrous_next; measured and lost): the temporal pass of the
     // NEXT frame, one 64x4 tile per workgroup every side_every steps, tiles claimed from a device counter (units 0 ..
@@ -352,7 +357,9 @@ __global__ __launch_bounds__(256) void atrous_direct_kernel(AtrousArgs a)
             else               tap_single<true>(acc, k, aux, t, kLogB3[adx] + kLogB3[ady], adx, ady, a.sigma_n);
         }
     }
-    a.out[i] = finish(lone.sw + acc.sw, lone.sl + acc.sl, lone.sr + acc.sr, lone.sg + acc.sg, lone.sv + acc.sv, ctr.c);
+    const float4 res = finish(lone.sw + acc.sw, lone.sl + acc.sl, lone.sr + acc.sr, lone.sg + acc.sg, lone.sv + acc.sv, ctr.c);
+    if (a.out8) a.out8[i] = u8_from_float4(res, true, float4_from_u8(a.albedo8[i], false, 0.0f));
+    else a.out[i] = res;
 }
 
 // ---------------------------------------------------------------------------------- stream
@@ -386,7 +393,7 @@ __device__ __forceinline__ float  lds_f1(const unsigned char* lds, int off) { re
 // with j even are processed from j0 = jlo & ~1, a pixel whose row falls outside [jlo, jhi) is
 // computed and dropped.  The pairing therefore depends only on (y, S), never on the row range or
 // the band decomposition: outputs are bit-identical for every decomposition.
-template <int S, int NP, bool EDGE>
+template <int S, int NP, bool EDGE, bool OUT8>
 __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned char* lds, const int tid,
                                                    const int x0, const int ybase, const int jlo, const int jhi)
 {
@@ -408,6 +415,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     float pvu[2], pvd[2], pzd[2], pvh = 0.0f;
     float zd_cur[2] = { 0.0f, 0.0f };
     float4 outA, outB;                                // results of the current step
+    unsigned pa8[2] = { 0u, 0u };                     // OUT8: the albedo bytes of the two output pixels of the current step
 
     // Global addresses are formed as (wave-uniform row base) + (lane index): the uniform part
     // stays in SGPRs (global_load ... saddr), only the lane offset lives in a VGPR.
@@ -527,7 +535,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     // of them queue up in the CU's texture address unit and every wave stalls at issue (tools/atrous_trace.py:
     // 16-23 % of a step).  Unconditional, at clamped rows (the last step fetches rows nobody uses; rows of
     // dropped outputs read something harmless), so no branch joins inside the loop.
-    constexpr int kPieces = 4 + C::NT + 7;
+    constexpr int kPieces = 4 + C::NT + 7 + (OUT8 ? 2 : 0);
     const int blo_i = max(g.buf_row0, 0), bhi_i = min(g.buf_row0 + g.buf_rows, g.H);
     auto clamp_row = [&](const int y) { return min(max(y, blo_i), bhi_i - 1); };
     auto prefetch_piece = [&](const int i, const int jb, const int jo) {
@@ -549,13 +557,26 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
             if (which == 0)      pvu[r] = (in_f + row_base(clamp_row(y - 1), x0) * 4 + 3)[col * 4];
             else if (which == 1) pvd[r] = (in_f + row_base(clamp_row(y + 1), x0) * 4 + 3)[col * 4];
             else                 pzd[r] = (nd_f + row_base(clamp_row(y + 1), x0) * 4 + 3)[col * 4];
-        } else {
+        } else if (i == 4 + C::NT + 6) {
             // halo columns x0-1 and x0+CW of the 4*NP variance rows: lanes 0 .. 8NP-1 keep theirs
             const int t8 = tid & (8 * NP - 1);
             const int ii = t8 >> 2, ud = (t8 >> 1) & 1, side = t8 & 1;
             const int yy = clamp_row(ybase + (jo + ii) * S + (ud ? 1 : -1));
             const int xx = side ? x0 + C::CW : x0 - 1;
             pvh = in_f[((size_t)(yy - g.buf_row0) * (size_t)g.W + (size_t)xx) * 4 + 3];
+        } else if constexpr (OUT8) {
+            // the albedo of THIS step's two output pixels (jo - ADV = the step being computed): consumed by write_out
+            const int r = i - (4 + C::NT + 7);
+            const int y = clamp_row(ybase + (jo - C::ADV + 2 * pr + r) * S);
+            pa8[r] = (reinterpret_cast<const unsigned*>(a.albedo8) + row_base(y, x0))[col];
+        }
+    };
+    // OUT8, frame-edge form: the same two fetches at the top of the step, per-lane tested
+    auto load_albedo = [&](const int j) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int jj = j + 2 * pr + i;
+            pa8[i] = (jj >= jlo && jj < jhi && xin) ? (reinterpret_cast<const unsigned*>(a.albedo8) + row_base(ybase + jj * S, x0))[col] : 0u;
         }
     };
 
@@ -753,7 +774,14 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
     auto write_out = [&](const int j) {
         const int jw = j + 2 * pr;
         const int yA = ybase + jw * S;
-        if (xin) {
+        if constexpr (OUT8) {
+            // modulate by the albedo, quantise, store bytes: rmd_convert_f32_to_u8's arithmetic on the registers of finish()
+            if (xin) {
+                auto al = [&](const unsigned v) { return float4_from_u8(make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24), false, 0.0f); };
+                if (jw >= jlo && jw < jhi) (a.out8 + row_base(yA, x0))[col] = u8_from_float4(outA, true, al(pa8[0]));
+                if (jw + 1 >= jlo && jw + 1 < jhi) (a.out8 + row_base(yA + S, x0))[col] = u8_from_float4(outB, true, al(pa8[1]));
+            }
+        } else if (xin) {
             // Non-temporal stores: the 133 MB a 4K launch writes are the expensive third of its traffic (the
             // skeleton without them runs at 5.4 TB/s, with them at 4.85), and nothing reads an output row
             // again before the next launch.  Launch for launch 131-145 -> 121-131 us, inside a frame 0.960 ->
@@ -831,6 +859,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         if (side_now && tid == 0) claim = atomicAdd(a.side_counter, 1u);
 #endif
         if (EDGE && more) { load_rows(j - 2 + C::NR); load_aux(j + C::ADV); }     // in flight during compute (interior form: inside compute)
+        if (EDGE && OUT8) load_albedo(j);
         RMD_PHASE(0)
         compute(j);
         RMD_PHASE(1)
@@ -866,7 +895,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
 }
 
 
-template <int S, int NP>
+template <int S, int NP, bool OUT8>
 __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(AtrousArgs a)
 {
 #ifdef RMD_ATROUS_TRACE
@@ -913,8 +942,8 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(A
     const int ytop = ybase + (j0 - 2) * S, ybot = ybase + (j0 + nsteps * C::ADV + 1) * S;
     const int blo = max(a.g.buf_row0, 0), bhi = min(a.g.buf_row0 + a.g.buf_rows, a.g.H);
     const bool edge = (x0 - 2 * S < 0) || (x0 + C::CW + 2 * S > a.g.W) || ytop < blo || ybot >= bhi;
-    if (edge) atrous_stream_body<S, NP, true>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
-    else      atrous_stream_body<S, NP, false>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+    if (edge) atrous_stream_body<S, NP, true, OUT8>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
+    else      atrous_stream_body<S, NP, false, OUT8>(a, atrous_lds, tid, x0, ybase, jlo, jhi);
 #ifdef RMD_ATROUS_TRACE
     __syncthreads();
     if (tid == 0 && pid < 8192) {
@@ -1014,18 +1043,27 @@ static double plan_stream(AtrousArgs& a)
     return best;
 }
 
-template <int S, int NP>
-static int launch_planned(const AtrousArgs& a, hipStream_t stream)
+template <int S, int NP, bool OUT8>
+static int launch_planned_as(const AtrousArgs& a, hipStream_t stream)
 {
     using C = StreamCfg<S, NP>;
     // per device, not per process: a host that drives several GPUs through rmd_set_device needs the
     // attribute (NP = 1 at step 16 asks for 65 568 bytes of LDS) on every one of them
-    if (first_use_on_device(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>)))
-        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP>),
+    if (first_use_on_device(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP, OUT8>)))
+        RMD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&atrous_stream_kernel<S, NP, OUT8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES + 16));
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S, NP>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES + 16, stream, a);   // + the side job's slot
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(atrous_stream_kernel<S, NP, OUT8>), dim3(a.per_xcd * kXcds), dim3(256), C::LDS_BYTES + 16, stream, a);   // + the side job's slot
     RMD_LAUNCH_CHECK("atrous_stream_kernel");
     return RMD_OK;
+}
+
+template <int S, int NP>
+static int launch_planned(const AtrousArgs& a, hipStream_t stream)
+{
+    // the byte-storing form exists for the library's default decomposition only (NP = 2); launch_atrous routes every
+    // other form through a float plane and a conversion launch
+    if constexpr (NP == 2) { if (a.out8) return launch_planned_as<S, NP, true>(a, stream); }
+    return launch_planned_as<S, NP, false>(a, stream);
 }
 
 template <int S, int NP>
@@ -1094,6 +1132,7 @@ extern "C" int rmd_debug_atrous_plan(int width, int height, int row0, int row1, 
     a.row0 = row0; a.row1 = row1; a.step = 1 << iteration; a.cus = cus;
     a.n_hi = a.band_h_hi = a.nblocks_hi = 0;
     a.b_row0 = a.b_row1 = a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
+    a.albedo8 = nullptr; a.out8 = nullptr;
 #ifdef RMD_EXPERIMENTS
     a.side_units = 0;
 #endif
@@ -1129,14 +1168,22 @@ extern "C" int rmd_svgf_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_para
 extern "C" int rmd_svgf_atrous2(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration,
                                 const float* in, float* out, int row0, int row1, int row0b, int row1b, void* stream)
 {
-    return launch_atrous(f, p, iteration, in, out, row0, row1, row0b, row1b, stream, nullptr);
+    return launch_atrous(f, p, iteration, in, out, row0, row1, row0b, row1b, stream, nullptr, nullptr);
 }
 
 int rmd::launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration, const float* in, float* out,
-                       int row0, int row1, int row0b, int row1b, void* stream, const AtrousSide* side)
+                       int row0, int row1, int row0b, int row1b, void* stream, const AtrousSide* side, const GBuffer8* g8)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_atrous: params is NULL");
+    // g8: the iteration stores modulated, quantised bytes to g8->denoised instead of floats to `out` (which may be NULL)
+    if (g8) {
+        if (!g8->albedo || !g8->denoised) return fail(RMD_E_NULL, "rmd_svgf_gbuffer_frame: albedo / denoised plane is NULL");
+        if (!aligned_to(g8->albedo, 4) || !aligned_to(g8->denoised, 4)) return fail(RMD_E_ALIGN, "rmd_svgf_gbuffer_frame: uchar4 planes must be 4-byte aligned");
+        if (side || row1b > row0b || !(p->atrous_variant == 0 || p->atrous_variant == 1 || p->atrous_variant == 3))
+            return fail(RMD_E_UNSUPPORTED, "rmd_svgf_gbuffer_frame: only the default / direct a-trous kernels store bytes");
+        if (!out) out = reinterpret_cast<float*>(g8->denoised);       // (not written; keeps the checks below meaningful)
+    }
     if (!in || !out || !f->nd) return fail(RMD_E_NULL, "rmd_svgf_atrous: in/out/nd plane is NULL");
     if (in == out) return fail(RMD_E_BUFFER, "rmd_svgf_atrous: in and out alias (taps cross pixels)");
     if (iteration < 0 || iteration > 12) return fail(RMD_E_PARAM, "rmd_svgf_atrous: iteration %d outside [0,12]", iteration);
@@ -1157,7 +1204,7 @@ int rmd::launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
         if (row0b < row1 || row1b > f->height) return fail(RMD_E_ROWS, "rmd_svgf_atrous2: second range [%d,%d) must lie behind the first [%d,%d)", row0b, row1b, row0, row1);
         if (int e = check_rows_in_buffer(f, row0b - 2 * s, row1b + 2 * s, "rmd_svgf_atrous2")) return e;
     }
-    if (!aligned_to(in, 16) || !aligned_to(out, 16) || !aligned_to(f->nd, 16))
+    if (!aligned_to(in, 16) || (!g8 && !aligned_to(out, 16)) || !aligned_to(f->nd, 16))
         return fail(RMD_E_ALIGN, "rmd_svgf_atrous: float4 planes must be 16-byte aligned");
 
     AtrousArgs a;
@@ -1171,6 +1218,7 @@ int rmd::launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
     a.b_row0 = two ? row0b : 0; a.b_row1 = two ? row1b : 0;
     a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
     a.nt_out = (double)(row1 - row0 + (two ? row1b - row0b : 0)) * f->width * 48.0 > 256.0e6 ? 1 : 0;
+    a.albedo8 = g8 ? g8->albedo : nullptr; a.out8 = g8 ? g8->denoised : nullptr;
 #ifdef RMD_EXPERIMENTS
     a.side_units = 0; a.side_every = 1; a.side_counter = nullptr;
     if (side && side->units > 0) { a.side = side->t; a.side_counter = side->counter; a.side_units = side->units; a.side_every = side->every < 1 ? 1 : side->every; }

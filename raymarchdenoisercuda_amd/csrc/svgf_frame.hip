@@ -72,7 +72,23 @@ struct rmd_svgf_context {
     unsigned char* tile_flags;
     int cur;            // index of the history set the next frame reads
     bool has_history;
+    // rmd_svgf_gbuffer_frame: the float (normal, depth) planes its front end writes, this frame's and the previous one's
+    // (allocated by the first such call), and whether the previous frame went through that call (nd[nd_cur ^ 1] is its nd)
+    float* nd[2];
+    int nd_cur;
+    bool nd_valid;
+    int* t_debug;       // optional int4 plane (rmd_svgf_context_set_debug_plane): T's bit-exact outputs of every frame
 };
+
+// A strip (rows beyond [row0,row1) exist in the frame) with a mid-frame exchange cannot run its a-trous iterations in one go:
+// the iteration behind the exchanged one would read halo rows nobody delivered.
+static int refuse_unexchanged_strip(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, const char* who)
+{
+    if (p && p->exchange_iteration >= 0 && (row0 > 0 || row1 < f->height))
+        return fail(RMD_E_PARAM, "%s: rows [%d,%d) are a strip of a %d-row frame and exchange_iteration = %d: drive the frame in parts "
+                    "(RMD_ATROUS_HEAD, the neighbour exchange, RMD_ATROUS_INTERIOR, RMD_ATROUS_TAIL)", who, row0, row1, f->height, p->exchange_iteration);
+    return RMD_OK;
+}
 
 extern "C" {
 
@@ -135,6 +151,8 @@ static int check_frame_call(const rmd_svgf_frame_desc* f, const rmd_svgf_params*
 
 int rmd_svgf_frame(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, void* stream)
 {
+    if (f && f->height > 0)
+        if (int e = refuse_unexchanged_strip(f, p, row0, row1, "rmd_svgf_frame")) return e;      // before anything is launched
     if (int e = rmd_svgf_frame_tv(f, p, row0, row1, stream)) return e;
     return rmd_svgf_frame_atrous(f, p, row0, row1, stream, nullptr);
 }
@@ -261,6 +279,8 @@ int rmd_svgf_frame_atrous_part(const rmd_svgf_frame_desc* f, const rmd_svgf_para
     if (part < RMD_ATROUS_ALL || part > RMD_ATROUS_TAIL) return fail(RMD_E_PARAM, "rmd_svgf_frame_atrous_part: part %d", part);
     if (part != RMD_ATROUS_ALL && r.mid < 0)
         return fail(RMD_E_PARAM, "rmd_svgf_frame_atrous_part: parts need rmd_svgf_params.exchange_iteration >= 0");
+    if (part == RMD_ATROUS_ALL)
+        if (int e = refuse_unexchanged_strip(f, p, row0, row1, "rmd_svgf_frame_atrous")) return e;
     const int H = f->height;
     const int n = p->iterations;
     for (int i = 0; i < n; ++i) {
@@ -319,6 +339,7 @@ int rmd_svgf_context_create(int width, int height, int buf_row0, int buf_rows, r
     c->width = width; c->height = height; c->buf_row0 = buf_row0; c->buf_rows = buf_rows;
     c->plane_bytes = (size_t)buf_rows * width * 16;
     c->cur = 0; c->has_history = false;
+    c->nd[0] = c->nd[1] = nullptr; c->nd_cur = 0; c->nd_valid = false; c->t_debug = nullptr;
     float** planes[] = { &c->hist_color[0], &c->hist_color[1], &c->hist_moments[0], &c->hist_moments[1],
                          &c->t_color, &c->v_color, &c->ping[0], &c->ping[1] };
     for (float** q : planes) *q = nullptr;
@@ -352,7 +373,7 @@ void rmd_svgf_context_destroy(rmd_svgf_context* c)
     if (!c) return;
     if (c->tile_flags) (void)hipFree(c->tile_flags);
     float* planes[] = { c->hist_color[0], c->hist_color[1], c->hist_moments[0], c->hist_moments[1],
-                        c->t_color, c->v_color, c->ping[0], c->ping[1] };
+                        c->t_color, c->v_color, c->ping[0], c->ping[1], c->nd[0], c->nd[1] };
     for (float* q : planes) if (q) (void)hipFree(q);
     delete c;
 }
@@ -361,6 +382,7 @@ int rmd_svgf_context_reset_history(rmd_svgf_context* c, void* stream)
 {
     if (!c) return fail(RMD_E_NULL, "rmd_svgf_context_reset_history: ctx is NULL");
     c->has_history = false;
+    c->nd_valid = false;
     for (int i = 0; i < 2; ++i) {
         RMD_HIP(hipMemsetAsync(c->hist_color[i], 0, c->plane_bytes, as_stream(stream)));
         RMD_HIP(hipMemsetAsync(c->hist_moments[i], 0, c->plane_bytes, as_stream(stream)));
@@ -391,13 +413,16 @@ static int context_frame_desc(rmd_svgf_context* c, const float* color, const flo
     *f = rmd_svgf_frame_desc{};
     if (int e = rmd_svgf_context_describe(c, f)) return e;
     f->color = color; f->nd = nd; f->motion = motion;
-    const bool use_hist = c->has_history && prev_nd != nullptr;
+    // (after a frame of rmd_svgf_gbuffer_frame the previous nd is the context's own plane, which the caller cannot name:
+    // the first float-plane frame behind it starts a new history)
+    const bool use_hist = c->has_history && prev_nd != nullptr && !c->nd_valid;
     f->prev_nd = use_hist ? prev_nd : nullptr;
     if (!use_hist) { f->hist_color = nullptr; f->hist_moments = nullptr; }
     f->out_color = out;
-    f->t_debug = nullptr; f->stats = nullptr;
+    f->t_debug = c->t_debug; f->stats = nullptr;
     return RMD_OK;
 }
+
 
 int rmd_svgf_context_denoise(rmd_svgf_context* c, const rmd_svgf_params* p, const float* color, const float* nd,
                              const float* motion, const float* prev_nd, float* out, int row0, int row1, void* stream)
@@ -407,6 +432,7 @@ int rmd_svgf_context_denoise(rmd_svgf_context* c, const rmd_svgf_params* p, cons
     if (int e = rmd_svgf_frame(&f, p, row0, row1, stream)) return e;
     c->cur ^= 1;            // this frame's t_moments / hist_color_out become the history
     c->has_history = true;
+    c->nd_valid = false;    // (the previous frame's nd is the caller's plane, not one of the context's)
     return RMD_OK;
 }
 
@@ -415,12 +441,16 @@ int rmd_svgf_context_denoise_part(rmd_svgf_context* c, const rmd_svgf_params* p,
 {
     rmd_svgf_frame_desc f;
     if (int e = context_frame_desc(c, color, nd, motion, prev_nd, out, &f)) return e;
-    if (part == RMD_ATROUS_HEAD)
+    if (part < RMD_ATROUS_ALL || part > RMD_ATROUS_TAIL) return fail(RMD_E_PARAM, "rmd_svgf_context_denoise_part: part %d", part);
+    // RMD_ATROUS_ALL is "everything in order" = rmd_svgf_context_denoise: T + V come first (they used to be skipped, so the
+    // iterations ran on a stale v_color and the history was rotated over it)
+    if (part == RMD_ATROUS_HEAD || part == RMD_ATROUS_ALL)
         if (int e = rmd_svgf_frame_tv(&f, p, row0, row1, stream)) return e;
     if (int e = rmd_svgf_frame_atrous_part(&f, p, row0, row1, stream, nullptr, part)) return e;
     if (part == RMD_ATROUS_TAIL || part == RMD_ATROUS_ALL) {
         c->cur ^= 1;
         c->has_history = true;
+        c->nd_valid = false;
     }
     return RMD_OK;
 }
@@ -434,6 +464,74 @@ int rmd_svgf_context_mid_plane(rmd_svgf_context* c, const rmd_svgf_params* p, fl
     rmd_svgf_frame_desc f = {};
     if (int e = rmd_svgf_context_describe(c, &f)) return e;
     return rmd_svgf_frame_iteration_plane(&f, p, mid[0], plane);
+}
+
+int rmd_svgf_context_set_debug_plane(rmd_svgf_context* c, int* t_debug)
+{
+    if (!c) return fail(RMD_E_NULL, "rmd_svgf_context_set_debug_plane: ctx is NULL");
+    if (!aligned_to(t_debug, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_context_set_debug_plane: the int4 plane must be 16-byte aligned");
+    c->t_debug = t_debug;
+    return RMD_OK;
+}
+
+// One frame of SVGF on the reference's own frame descriptor (include/gbuffer.h:6-14): uchar4 render / albedo / normal in,
+// uchar4 denoised out, six launches.  The 8-bit ends are fused into the first and the last of them (pixel_convert.h).
+int rmd_svgf_gbuffer_frame(rmd_gbuffer frame, rmd_svgf_context* c, const rmd_svgf_params* p, const float* motion,
+                           float albedo_eps, void* stream)
+{
+    if (!c || !p) return fail(RMD_E_NULL, "rmd_svgf_gbuffer_frame: ctx / params is NULL");
+    if (frame.shape.x != c->width || frame.shape.y != c->height)
+        return fail(RMD_E_SHAPE, "rmd_svgf_gbuffer_frame: GBuffer is %dx%d, the context %dx%d", frame.shape.x, frame.shape.y, c->width, c->height);
+    if (c->buf_row0 != 0 || c->buf_rows != c->height)
+        return fail(RMD_E_ROWS, "rmd_svgf_gbuffer_frame: the GBuffer holds whole frames; the context holds rows [%d,%d) of %d",
+                    c->buf_row0, c->buf_row0 + c->buf_rows, c->height);
+    if (!frame.render || !frame.albedo || !frame.normal || !frame.denoised)
+        return fail(RMD_E_NULL, "rmd_svgf_gbuffer_frame: render / albedo / normal / denoised must all be set");
+    if (frame.denoised == frame.render || frame.denoised == frame.albedo || frame.denoised == frame.normal)
+        return fail(RMD_E_BUFFER, "rmd_svgf_gbuffer_frame: denoised aliases an input plane");
+    Reach r;
+    if (int e = compute_reach(p, r)) return e;
+    if (r.mid >= 0) return fail(RMD_E_PARAM, "rmd_svgf_gbuffer_frame: whole frames only (exchange_iteration must be -1)");
+    if (p->var_radius != 3 || p->tv_workgroups != 0 || p->var_h_threshold > 256)
+        return fail(RMD_E_UNSUPPORTED, "rmd_svgf_gbuffer_frame: the 8-bit front end lives in the fused T+V launch (var_radius 3, "
+                    "tv_workgroups 0, var_h_threshold <= 256); other settings take the float planes (rmd_convert_u8_to_f32, rmd_svgf_context_denoise)");
+    for (int k = 0; k < 2; ++k)
+        if (!c->nd[k]) {
+            RMD_HIP(hipMalloc((void**)&c->nd[k], c->plane_bytes));
+            RMD_HIP(hipMemsetAsync(c->nd[k], 0, c->plane_bytes, as_stream(stream)));
+        }
+    const int H = c->height, n = p->iterations;
+    rmd_svgf_frame_desc f = {};
+    if (int e = rmd_svgf_context_describe(c, &f)) return e;
+    const bool use_hist = c->has_history && c->nd_valid;
+    if (!use_hist) { f.hist_color = nullptr; f.hist_moments = nullptr; }
+    f.color = nullptr; f.motion = motion;
+    f.nd = c->nd[c->nd_cur];
+    f.prev_nd = use_hist ? c->nd[c->nd_cur ^ 1] : nullptr;
+    f.t_debug = c->t_debug; f.stats = nullptr;
+    // the last iteration stores bytes; if it is also the history iteration its floats are needed too: it then writes
+    // hist_color_out and a conversion launch follows (not the default: hist_iteration = 0 of 5)
+    const bool last_is_hist = p->hist_iteration == n - 1;
+    f.out_color = last_is_hist ? f.hist_color_out : nullptr;
+    if ((n >= 2 + (last_is_hist ? 0 : 1) && !f.ping[0]) || !f.v_color || !f.hist_color_out)
+        return fail(RMD_E_NULL, "rmd_svgf_gbuffer_frame: context planes missing");
+    const GBuffer8 g8 = { reinterpret_cast<const uchar4*>(frame.render), reinterpret_cast<const uchar4*>(frame.albedo),
+                          reinterpret_cast<const uchar4*>(frame.normal), reinterpret_cast<uchar4*>(frame.denoised), albedo_eps };
+    if (int e = launch_temporal_variance(&f, p, 0, H, 0, H, stream, &g8)) return e;
+    for (int i = 0; i < n; ++i) {
+        const float* in;
+        float* out;
+        atrous_route(&f, p, i, &in, &out);
+        const bool bytes = i == n - 1 && !last_is_hist;
+        if (int e = launch_atrous(&f, p, i, in, out, 0, H, 0, 0, stream, nullptr, bytes ? &g8 : nullptr)) return e;
+    }
+    if (last_is_hist)
+        if (int e = launch_modulate_to_u8(f.hist_color_out, frame.albedo, frame.denoised, (size_t)c->width * H, stream)) return e;
+    c->cur ^= 1;
+    c->has_history = true;
+    c->nd_cur ^= 1;
+    c->nd_valid = true;
+    return RMD_OK;
 }
 
 int rmd_svgf_context_history(rmd_svgf_context* c, float** hist_color, float** hist_moments)

@@ -29,6 +29,9 @@ struct FusedVArgs {
     int tiles_x, tiles_y;     // the launch's tile grid (one workgroup per tile, dealt out edges first)
 };
 
+// IN8 (rmd_svgf_gbuffer_frame): the same launch with the 8-bit front end of temporal_pixel<true> -- the workgroup reads the
+// GBuffer's uchar4 render / albedo / normal planes (12 B/px instead of 32 B/px of float planes) and writes the float nd plane.
+template <bool IN8>
 __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArgs a, FusedVArgs v)
 {
     // 20 144 B of LDS: eight workgroups per CU, the occupancy of the plain T kernel (the pass is latency-bound: with two
@@ -56,14 +59,15 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
     const int x0 = tile_x * 64, y0 = tile_y * 4;
     const int x = x0 + lx, y = y0 + ly;
     const bool active = x < g.W && y >= a.row0 && y < a.row1;
-    float4 tc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 tc = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nd_own = tc;
     int h = 0;
     bool spatial = false;
     if (active) {
         const size_t i = pix_index(g, x, y);
         float4 mom;
         int4 dbg;
-        temporal_pixel(a, x, y, tc, mom, dbg);
+        temporal_pixel<IN8>(a, x, y, tc, mom, dbg, nd_own);
+        if constexpr (IN8) a.nd_out[i] = nd_own;
         a.t_moments[i] = mom;
         if (a.t_debug) a.t_debug[i] = dbg;
         h = dbg.w;
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
     const int by0 = (m0 ? 0 : m1 ? 1 : m2 ? 2 : 3) - kVR, by1 = (m3 ? 3 : m2 ? 2 : m1 ? 1 : 0) + kVR;
     if (active) {
         scr[ly + kVR][lx + kVR] = tc.x; scg[ly + kVR][lx + kVR] = tc.y; scb[ly + kVR][lx + kVR] = tc.z;
-        sn[ly + kVR][lx + kVR] = a.nd[pix_index(g, x, y)];
+        if constexpr (IN8) sn[ly + kVR][lx + kVR] = nd_own;
+        else sn[ly + kVR][lx + kVR] = a.nd[pix_index(g, x, y)];
     }
     for (int q = threadIdx.x; q < kVW * kVH; q += 256) {
         const int ry = q / kVW, rx = q - ry * kVW;
@@ -95,11 +100,12 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
         // pixels outside the frame are never tapped (A.V skips them); neither are rows outside T's range: V's rows lie
         // at least 3 rows inside it wherever the frame goes on (launch_temporal_variance)
         if (tx < 0 || tx >= g.W || ty < a.row0 || ty >= a.row1) continue;
-        float4 hc, mom;
+        float4 hc, mom, hn;
         int4 dbg;
-        temporal_pixel(a, tx, ty, hc, mom, dbg);
+        temporal_pixel<IN8>(a, tx, ty, hc, mom, dbg, hn);
         scr[ry][rx] = hc.x; scg[ry][rx] = hc.y; scb[ry][rx] = hc.z;
-        sn[ry][rx] = a.nd[pix_index(g, tx, ty)];
+        if constexpr (IN8) sn[ry][rx] = hn;
+        else sn[ry][rx] = a.nd[pix_index(g, tx, ty)];
     }
     // ---- the short-history pixels of the tile, compacted to the first lanes (a wave with one such lane pays for the whole
     // 49-tap body), as svgf_variance_tile_kernel does
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
         float4 o = variance_window_lds([&](int ry, int rx) { return make_float4(scr[ry][rx], scg[ry][rx], scb[ry][rx], 0.0f); },
                                        [&](int ry, int rx) { return sn[ry][rx]; }, px, py, x0 + px, y0 + py, g, v.sigma_n, v.sigma_z, id >> 8, keep);
         if (keep) {                                        // weights vanished (normals that break the unit-length contract): the pixel
-            float4 mom;                                    // keeps T's value, whose variance only the lane that computed it had
+            float4 mom, kn;                                // keeps T's value, whose variance only the lane that computed it had
             int4 dbg;
-            temporal_pixel(a, x0 + px, y0 + py, o, mom, dbg);
+            temporal_pixel<IN8>(a, x0 + px, y0 + py, o, mom, dbg, kn);
         }
         a.v_color[pix_index(g, x0 + px, y0 + py)] = o;
     }
@@ -202,6 +208,7 @@ int rmd::make_temporal_args(const rmd_svgf_frame_desc* f, const rmd_svgf_params*
     a.prev_nd = (const float4*)f->prev_nd;
     a.t_color = (float4*)f->t_color; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
     a.v_color = nullptr;
+    a.render8 = a.albedo8 = a.normal8 = nullptr; a.nd_out = nullptr; a.albedo_eps = 0.0f;
     a.sparse_t_color = (fused && sparse_t_color) ? 1 : 0;
     a.tile_flags = nullptr; a.tiles_x = (f->width + 63) / 64; a.var_h_threshold = p->var_h_threshold;
     if (fused) {
@@ -250,11 +257,20 @@ int rmd::launch_temporal_claim(const AtrousSide& side, void* stream)
 #endif
 
 // T + V of a whole frame in one launch (svgf_temporal_variance_kernel): T on rows [row0,row1), V on [v_row0,v_row1).
-int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, int v_row0, int v_row1, void* stream)
+int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int row0, int row1, int v_row0, int v_row1, void* stream,
+                                  const GBuffer8* g8)
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_frame_tv: params is NULL");
-    if (!f->color || !f->nd || !f->motion || !f->t_moments || !f->v_color)
+    // 8-bit front end: render / albedo / normal are the inputs, f->nd is WRITTEN, f->color is not used, f->motion may be NULL
+    if (g8) {
+        if (!g8->render || !g8->albedo || !g8->normal || !f->nd || !f->t_moments || !f->v_color)
+            return fail(RMD_E_NULL, "rmd_svgf_gbuffer_frame: a required plane is NULL");
+        if (!aligned_to(g8->render, 4) || !aligned_to(g8->albedo, 4) || !aligned_to(g8->normal, 4))
+            return fail(RMD_E_ALIGN, "rmd_svgf_gbuffer_frame: uchar4 planes must be 4-byte aligned");
+        if (!(g8->albedo_eps > 0.0f)) return fail(RMD_E_PARAM, "rmd_svgf_gbuffer_frame: albedo_eps must be > 0");
+        if (f->nd == f->prev_nd) return fail(RMD_E_BUFFER, "rmd_svgf_gbuffer_frame: the nd plane written aliases prev_nd");
+    } else if (!f->color || !f->nd || !f->motion || !f->t_moments || !f->v_color)
         return fail(RMD_E_NULL, "rmd_svgf_frame_tv: a required plane is NULL");
     const bool has_hist = f->hist_color && f->hist_moments && f->prev_nd;
     if (!has_hist && (f->hist_color || f->hist_moments || f->prev_nd))
@@ -269,7 +285,7 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
     if (int e = check_rows_in_buffer(f, row0, row1 + 1, "rmd_svgf_frame_tv (current frame)")) return e;
     if (has_hist)
         if (int e = check_rows_in_buffer(f, row0 - p->max_motion_rows, row1 + p->max_motion_rows, "rmd_svgf_frame_tv (history)")) return e;
-    const void* planes16[] = { f->color, f->nd, f->hist_color, f->hist_moments, f->prev_nd, f->v_color, f->t_moments, f->t_debug };
+    const void* planes16[] = { g8 ? nullptr : f->color, f->nd, f->hist_color, f->hist_moments, f->prev_nd, f->v_color, f->t_moments, f->t_debug };
     for (const void* q : planes16)
         if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_frame_tv: float4 planes must be 16-byte aligned");
     if (!aligned_to(f->motion, 8)) return fail(RMD_E_ALIGN, "rmd_svgf_frame_tv: motion must be 8-byte aligned");
@@ -277,6 +293,11 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
     TemporalArgs a;
     a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
     a.color = (const float4*)f->color; a.nd = (const float4*)f->nd; a.motion = (const float2*)f->motion;
+    a.render8 = a.albedo8 = a.normal8 = nullptr; a.nd_out = nullptr; a.albedo_eps = 0.0f;
+    if (g8) {
+        a.color = nullptr; a.nd = nullptr;
+        a.render8 = g8->render; a.albedo8 = g8->albedo; a.normal8 = g8->normal; a.nd_out = (float4*)f->nd; a.albedo_eps = g8->albedo_eps;
+    }
     a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float4*)f->hist_moments;
     a.prev_nd = (const float4*)f->prev_nd;
     a.t_color = nullptr; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
@@ -288,7 +309,9 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
     const int tiles_x = (f->width + 63) / 64, tiles_y = (row1 - 1) / 4 - row0 / 4 + 1;
     FusedVArgs v = { v_row0, v_row1, p->var_h_threshold, p->sigma_n, p->sigma_z, tiles_x, tiles_y };
-    hipLaunchKernelGGL(svgf_temporal_variance_kernel, dim3((unsigned)tiles_x * (unsigned)tiles_y), dim3(256), 0, as_stream(stream), a, v);
+    const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y);
+    if (g8) hipLaunchKernelGGL(HIP_KERNEL_NAME(svgf_temporal_variance_kernel<true>), grid, dim3(256), 0, as_stream(stream), a, v);
+    else    hipLaunchKernelGGL(HIP_KERNEL_NAME(svgf_temporal_variance_kernel<false>), grid, dim3(256), 0, as_stream(stream), a, v);
     RMD_LAUNCH_CHECK("svgf_temporal_variance_kernel");
     return RMD_OK;
 }

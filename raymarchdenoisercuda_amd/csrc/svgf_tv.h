@@ -3,6 +3,7 @@
 // staged in LDS.  One definition each, so every launch form produces the same bits.
 #pragma once
 #include "common.h"
+#include "pixel_convert.h"
 
 namespace rmd {
 
@@ -19,6 +20,13 @@ struct TemporalArgs {
     int row0, row1;
     float alpha_color, alpha_moments, k_z, k_n;
     int h_max, max_motion_rows;
+    // 8-bit front end (rmd_svgf_gbuffer_frame, the IN8 instantiations): color / nd are not read -- the inputs are the uchar4
+    // planes of the reference's GBuffer (include/gbuffer.h:9-12), converted and demodulated in registers with the functions of
+    // the standalone conversion kernels (pixel_convert.h) -- and the float nd plane is WRITTEN, once, for the a-trous passes
+    // and as the next frame's prev_nd.  motion may be NULL in either form: a static camera.
+    const uchar4* render8; const uchar4* albedo8; const uchar4* normal8;
+    float4* nd_out;
+    float albedo_eps;
 };
 
 // The temporal pass of the NEXT frame as a side job of the a-trous launches of this one (svgf_atrous.hip,
@@ -35,22 +43,32 @@ int make_temporal_args(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
                        TemporalArgs* out);
 // the tiles of `side` nobody has claimed yet (a grid of workgroups that claim until the counter runs out)
 int launch_temporal_claim(const AtrousSide& side, void* stream);
+// g8 != NULL: the iteration stores modulated, quantised bytes to g8->denoised (pixel_convert.h) instead of floats to `out`
 int launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, int iteration, const float* in, float* out,
-                  int row0, int row1, int row0b, int row1b, void* stream, const AtrousSide* side);
+                  int row0, int row1, int row0b, int row1b, void* stream, const AtrousSide* side, const GBuffer8* g8 = nullptr);
 unsigned* side_counter_on_device();        // one zero-initialised word per device (runtime.hip)
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 
 // Appendix A.T for ONE pixel (x, y) inside the frame and the buffer: returns c' + variance in `tc`, the moments in `mom`,
-// the bit-exact integer outputs in `dbg`.  Stores nothing.
-__device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int x, const int y, float4& tc, float4& mom, int4& dbg)
+// the bit-exact integer outputs in `dbg`, the pixel's (normal, depth) in `nd`.  Stores nothing.
+// IN8: illumination and (normal, depth) come from the GBuffer's uchar4 planes -- rmd_convert_u8_to_f32 (render, albedo: c/255;
+// normal: c/255 renormalised, w/255 = depth) and rmd_demodulate in registers, the operations of those kernels in their order.
+template <bool IN8 = false>
+__device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int x, const int y, float4& tc, float4& mom, int4& dbg, float4& nd)
 {
     const Geom g = a.g;
     const size_t i = pix_index(g, x, y);
 
-    const float4 c = a.color[i];
-    const float4 nd = a.nd[i];
-    const float2 m = a.motion[i];
+    float4 c;
+    if constexpr (IN8) {
+        c = demodulated(float4_from_u8(a.render8[i], false, 0.0f), float4_from_u8(a.albedo8[i], false, 0.0f), a.albedo_eps);
+        nd = float4_from_u8(a.normal8[i], true, -1.0f);
+    } else {
+        c = a.color[i];
+        nd = a.nd[i];
+    }
+    const float2 m = a.motion ? a.motion[i] : make_float2(0.0f, 0.0f);
 
     // A.T.1
     const float qx = (float)x + m.x, qy = (float)y + m.y;
@@ -61,8 +79,14 @@ __device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int 
 
     // A.T.2: depth gradient by forward differences clamped at the border
     const int x1 = min(x + 1, g.W - 1), y1 = min(y + 1, g.H - 1);
-    const float zr = a.nd[pix_index(g, x1, y)].w;
-    const float zd = a.nd[pix_index(g, x, y1)].w;
+    float zr, zd;
+    if constexpr (IN8) {
+        zr = unit_from_u8(reinterpret_cast<const unsigned char*>(a.normal8 + pix_index(g, x1, y))[3]);
+        zd = unit_from_u8(reinterpret_cast<const unsigned char*>(a.normal8 + pix_index(g, x, y1))[3]);
+    } else {
+        zr = a.nd[pix_index(g, x1, y)].w;
+        zd = a.nd[pix_index(g, x, y1)].w;
+    }
     const float gz = fabsf(zr - nd.w) + fabsf(zd - nd.w);
     const float zthr = a.k_z * (gz + 1e-2f);
     const bool p_zero = is_zero3(nd);
@@ -148,9 +172,9 @@ __device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int t
     size_t i = 0;
     if (active) {
         i = pix_index(g, x, y);
-        float4 mom;
+        float4 mom, nd;
         int4 dbg;
-        temporal_pixel(a, x, y, tc, mom, dbg);
+        temporal_pixel(a, x, y, tc, mom, dbg, nd);
         if (!a.sparse_t_color) a.t_color[i] = tc;
         if (a.v_color) a.v_color[i] = tc;
         a.t_moments[i] = mom;

@@ -222,26 +222,20 @@ TEST(IMAGE)
     expect(threw, "a missing file throws std::runtime_error");
 }
 
-// ---- SVGF on the Cornell G-buffer: PNG planes -> float planes -> T+V+5A -> uchar4 -> PNG ------
+// ---- SVGF on the Cornell G-buffer: PNG planes -> ONE call per frame on the GBuffer -> PNG ------------------------
+// (svgfDenoise = rmd_svgf_gbuffer_frame: the uchar4 planes go in as they are; conversion to float, renormalisation of the normals,
+// demodulation by albedo, and modulation + quantisation of the result run inside the frame's first and last launch)
 TEST(SVGF_CORNELL)
 {
     CudaGBuffer g;
     g.openImages(dataPath());
     const int W = g.shape.x, H = g.shape.y;
     const size_t n = (size_t)W * H;
-    CudaVector<float> color(4 * n), nd(4 * n), albedo(4 * n), motion(2 * n), out(4 * n);
-    // everything below is queued behind the asynchronous upload of openImages on the same (default) stream
-    rmdCheck(rmd_convert_u8_to_f32((rmd_uchar4*)g.render, color.data(), n, 0, 0.0f, nullptr), "convert render");
-    rmdCheck(rmd_convert_u8_to_f32((rmd_uchar4*)g.albedo, albedo.data(), n, 0, 0.0f, nullptr), "convert albedo");
-    rmdCheck(rmd_convert_u8_to_f32((rmd_uchar4*)g.normal, nd.data(), n, 1, 1.0f, nullptr), "convert normal");
-    // SVGF filters illumination = radiance / albedo; the albedo comes back when the result is quantised
-    rmdCheck(rmd_demodulate(color.data(), albedo.data(), color.data(), n, 1.0f / 255.0f, nullptr), "demodulate");
-    motion.fill(0);
     SvgfContext ctx(W, H);
     const SvgfParams p = svgfDefaultParams();
-    for (int f = 0; f < 3; ++f)                          // static camera: history accumulates
-        ctx.denoise(p, color.data(), nd.data(), motion.data(), f ? nd.data() : nullptr, out.data(), 0, H);
-    rmdCheck(rmd_convert_f32_to_u8(out.data(), albedo.data(), (rmd_uchar4*)g.denoised, n, nullptr), "modulate + convert denoised");
+    // queued behind the asynchronous upload of openImages on the same (default) stream
+    for (int f = 0; f < 3; ++f)                          // static camera (motion = NULL): history accumulates
+        svgfDenoise(g, ctx, p);
     uchar4* host = g.download();
     CpuVector<uchar4> noisy;
     g.renderVec.copyTo(noisy);

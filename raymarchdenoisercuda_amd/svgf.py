@@ -179,8 +179,6 @@ class SvgfDenoiser:
         self.tile_flags = torch.zeros(tile_flags_bytes(width, height), dtype=torch.uint8, device=device)
         self.cur = 0
         self.has_history = False
-        self._tv_done_for = None     # data pointers of the frame whose T + V the previous call already ran (next_frame)
-        self._keep_next = None
         self.prev_nd = None
         self.pipelined = pipelined
         self._ev_hist = C.c_void_p()
@@ -204,7 +202,6 @@ class SvgfDenoiser:
     def reset_history(self):
         self.has_history = False
         self.prev_nd = None
-        self._tv_done_for = None
 
     def history(self):
         """(hist_color, hist_moments) the NEXT denoise call reads."""
@@ -218,8 +215,8 @@ class SvgfDenoiser:
             torch.cuda.current_stream().synchronize()
 
     def describe(self, color, nd, motion, out, ahead=False):
-        """The frame descriptor of the next denoise call -- or, with ahead=True, of the call AFTER it (its history planes are
-        the ones the next call writes, its prev_nd the next call's nd: pass that as `ahead`)."""
+        """The frame descriptor of the next denoise call -- or, with ahead=<the next call's nd>, of the call AFTER it (its
+        history planes are the ones the next call writes, its prev_nd the next call's nd)."""
         cur = self.cur ^ 1 if ahead is not False else self.cur
         prev_nd = ahead if ahead is not False else self.prev_nd
         use_hist = ahead is not False or (self.has_history and self.prev_nd is not None)
@@ -245,7 +242,7 @@ class SvgfDenoiser:
                 dst, pp = self.ping[pp], pp ^ 1
         return dst
 
-    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None, hooks=None, next_frame=None):
+    def denoise(self, color, nd, motion, out=None, row0=None, row1=None, stream=None, before_tv=None, hooks=None, _tv_done=False):
         """One frame.  `nd` is borrowed until the next call (it becomes prev_nd).  `before_tv` is
         called just before T is launched, on the stream T runs on (a row-strip deployment completes
         its history halo there).  Serial form: runs on `stream` (default: torch's current stream).
@@ -263,26 +260,9 @@ class SvgfDenoiser:
         row0 = max(self.buf_row0, 0) if row0 is None else row0
         row1 = min(self.buf_row0 + self.buf_rows, self.height) if row1 is None else row1
         d = self.describe(color, nd, motion, out)
-        # next_frame = (color, nd, motion) of the FOLLOWING call (serial form, no hooks): its temporal pass rides inside this
-        # frame's a-trous launches (rmd_svgf_frame_atrous_next) and the following call then skips T + V
-        tv_done = self._tv_done_for is not None
-        if tv_done and self._tv_done_for != tuple(t.data_ptr() for t in (color, nd, motion)):
-            raise ValueError("the previous denoise() call ran this frame's temporal pass on the planes it was given as next_frame; "
-                             "call denoise() with those planes")
-        self._tv_done_for = None
-        if next_frame is not None:
-            if self.pipelined or hooks is not None or before_tv is not None or frame_mid_exchange(self.params)[0] >= 0:
-                raise ValueError("next_frame needs the serial frame without hooks or a mid-frame exchange")
-            s_ptr = _stream_ptr(torch.cuda.current_stream() if stream is None else stream)
-            p = self.params
-            if not tv_done:
-                check(lib.rmd_svgf_frame_tv(C.byref(d), C.byref(p), row0, row1, s_ptr))
-            nc, nnd, nm = next_frame
-            dn = self.describe(nc, nnd, nm, out, ahead=nd)
-            check(lib.rmd_svgf_frame_atrous_next(C.byref(d), C.byref(p), row0, row1, s_ptr, None, C.byref(dn)))
-            self._tv_done_for = tuple(t.data_ptr() for t in (nc, nnd, nm))
-            self._keep_next = next_frame                 # the planes stay referenced until the following call
-        elif not self.pipelined:
+        tv_done = _tv_done          # (experiments.NextFrameDenoiser: T + V of this frame already ran inside the previous frame's launches)
+        is_strip = row0 > 0 or row1 < self.height
+        if not self.pipelined:
             if before_tv is not None:
                 before_tv()
             # the caller's CURRENT torch stream unless told otherwise (NULL would be unordered with a
@@ -290,6 +270,10 @@ class SvgfDenoiser:
             s_ptr = _stream_ptr(torch.cuda.current_stream() if stream is None else stream)
             mid = frame_mid_exchange(self.params)[0]
             p = self.params
+            if mid >= 0 and is_strip and (hooks is None or not hasattr(hooks, "mid_ready") or not hasattr(hooks, "mid_wait")):
+                # without the exchange the iteration behind `mid` would read halo rows of the previous frame
+                raise ValueError(f"rows [{row0},{row1}) are a strip and exchange_iteration = {mid}: denoise() needs hooks.mid_ready / "
+                                 "hooks.mid_wait to exchange the halo rows (sharding.ShardedDenoiser)")
             # the history-ready event only where somebody waits for it (a row-strip deployment): an event record between two
             # launches costs ~6 us of idle GPU on this stack (tools/frame_gaps.py)
             ev_hist = self._ev_hist if hooks is not None and hasattr(hooks, "hist_ready") else None
@@ -316,7 +300,7 @@ class SvgfDenoiser:
                     hooks.hist_ready(ev_hist)
         else:
             if tv_done:
-                raise ValueError("next_frame and the pipelined form do not mix")
+                raise ValueError("the next-frame side job and the pipelined form do not mix")
             if frame_mid_exchange(self.params)[0] >= 0:
                 raise ValueError("exchange_iteration >= 0 needs the serial (single-stream) frame: pipelined=False")
             sa, sb = self.stream_a, self.stream_b
@@ -342,3 +326,56 @@ class SvgfDenoiser:
         self.has_history = True
         self.prev_nd = nd
         return out
+
+
+class GBufferDenoiser:
+    """SVGF on the reference's own frame descriptor (include/gbuffer.h:6-14): one call per frame, uint8 [H, W, 4] render /
+    albedo / normal planes in, uint8 denoised out (rmd_svgf_gbuffer_frame; the 8-bit ends run inside the frame's first and
+    last launch).  The cross-frame state lives in the C context (rmd_svgf_context_*), not in torch tensors."""
+
+    def __init__(self, width, height, params=None, albedo_eps=1.0 / 255.0, debug=False, device="cuda"):
+        self.width, self.height = width, height
+        self.params = params if params is not None else default_params()
+        self.albedo_eps = float(albedo_eps)
+        self._ctx = C.c_void_p()
+        check(lib.rmd_svgf_context_create(width, height, 0, height, C.byref(self._ctx)))
+        self.t_debug = torch.zeros((height, width, 4), dtype=torch.int32, device=device) if debug else None
+        if debug:
+            check(lib.rmd_svgf_context_set_debug_plane(self._ctx, self.t_debug.data_ptr()))
+
+    def __del__(self):
+        if sys.is_finalizing():            # the HIP runtime may already be gone
+            return
+        ctx = getattr(self, "_ctx", None)
+        if ctx:
+            lib.rmd_svgf_context_destroy(ctx)
+            self._ctx = None
+
+    def reset_history(self, stream=None):
+        check(lib.rmd_svgf_context_reset_history(self._ctx, _stream_ptr(stream)))
+
+    def frame(self, render, albedo, normal, denoised=None, motion=None, stream=None):
+        """One frame; returns `denoised` (uint8 [H, W, 4]).  motion: float32 [H, W, 2] (current -> previous) or None = static."""
+        from .filter import make_gbuffer
+        if denoised is None:
+            denoised = torch.empty_like(render)
+        if tuple(render.shape) != (self.height, self.width, 4):
+            raise ValueError(f"render: shape {tuple(render.shape)} != {(self.height, self.width, 4)}")
+        g = make_gbuffer(render, denoised, normal=normal, albedo=albedo)
+        m = _ptr(motion, "motion", self.height, self.width, 2)
+        s_ptr = _stream_ptr(torch.cuda.current_stream() if stream is None else stream)
+        check(lib.rmd_svgf_gbuffer_frame(g, self._ctx, C.byref(self.params), m, self.albedo_eps, s_ptr))
+        return denoised
+
+    def history(self):
+        """Copies of (hist_color, hist_moments) the NEXT frame reads, as float32 [H, W, 4] CUDA tensors."""
+        hc, hm = C.c_void_p(), C.c_void_p()
+        check(lib.rmd_svgf_context_history(self._ctx, C.byref(hc), C.byref(hm)))
+        out = []
+        for ptr in (hc, hm):
+            t = torch.empty((self.height, self.width, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.current_stream().synchronize()
+            check(lib.rmd_memcpy_d2d(t.data_ptr(), ptr, t.numel() * 4, None))
+            check(lib.rmd_device_sync())
+            out.append(t)
+        return tuple(out)

@@ -92,6 +92,7 @@ def _load():
     lib.orc_demodulate.argtypes = [P, P, P, C.c_size_t, C.c_float]
     lib.orc_demodulate.restype = None
     lib.orc_hardware_threads.restype = C.c_int
+    lib.orc_unit_from_u8_mismatches.restype = C.c_int
     for f in (lib.orc_box_level, lib.orc_box_filter, lib.orc_box_filter_mt, lib.orc_svgf_temporal, lib.orc_svgf_variance,
               lib.orc_svgf_atrous, lib.orc_svgf_frame, lib.orc_svgf_pass_mt, lib.orc_synth_gbuffer,
               lib.orc_convert_u8_to_f32, lib.orc_convert_f32_to_u8):
@@ -241,6 +242,21 @@ def demodulate(radiance, albedo, eps=1e-3):
     out = np.zeros(r.shape, np.float32)
     lib.orc_demodulate(_p(r), _p(a), _p(out), r.shape[0] * r.shape[1], eps)
     return out
+
+
+def gbuffer_frame(render_u8, albedo_u8, normal_u8, p, motion=None, hist=None, albedo_eps=1.0 / 255.0, threads=4):
+    """The composition rmd_svgf_gbuffer_frame is defined as (include/rmd_api.h): orc_convert_u8_to_f32 (render, albedo: c/255;
+    normal: renormalised, w/255 = depth) -> orc_demodulate -> orc_svgf_frame -> orc_convert_f32_to_u8 (x albedo).
+    hist = (hist_color, hist_moments, prev_nd) of the previous frame or None.  Returns (denoised uint8, Frame)."""
+    h, w, _ = render_u8.shape
+    color = demodulate(convert_u8_to_f32(render_u8, False, 0.0), convert_u8_to_f32(albedo_u8, False, 0.0), albedo_eps)
+    albedo = convert_u8_to_f32(albedo_u8, False, 0.0)
+    nd = convert_u8_to_f32(normal_u8, True, -1.0)
+    m = np.zeros((h, w, 2), np.float32) if motion is None else motion
+    hc, hm, pn = hist if hist is not None else (None, None, None)
+    fr = Frame(w, h, color, nd, m, hc, hm, pn)
+    frame(fr, p, threads=threads)
+    return convert_f32_to_u8(fr.out_color, albedo), fr
 
 
 def hardware_threads():

@@ -229,7 +229,8 @@ def test_next_frames_temporal_pass_inside_the_atrous_launches(rmd, cuda, width, 
     frames = 6
     serial, den_s = run_sequence(rmd, width, height, frames, False, p)
     inputs = [rmd.svgf.synth_gbuffer(width, height, f) for f in range(frames)]
-    den = rmd.SvgfDenoiser(width, height, params=p)
+    from raymarchdenoisercuda_amd.experiments import NextFrameDenoiser
+    den = NextFrameDenoiser(width, height, params=p)
     outs = [torch.empty_like(inputs[0][0]) for _ in range(frames)]
     for f in range(frames):
         den.denoise(*inputs[f], out=outs[f], next_frame=inputs[f + 1] if f + 1 < frames else None)
@@ -247,7 +248,8 @@ def test_next_frame_side_job_is_refused_by_the_product_build(rmd, cuda):
     if rmd.HAS_EXPERIMENTS:
         pytest.skip("experiments build")
     p = rmd.default_params()
-    den = rmd.SvgfDenoiser(128, 64, params=p)
+    from raymarchdenoisercuda_amd.experiments import NextFrameDenoiser
+    den = NextFrameDenoiser(128, 64, params=p)
     a, b = rmd.svgf.synth_gbuffer(128, 64, 0), rmd.svgf.synth_gbuffer(128, 64, 1)
     with pytest.raises(rmd.RmdError) as e:
         den.denoise(*a, next_frame=b)

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import raymarchdenoisercuda_amd as rmd  # noqa: E402
+from raymarchdenoisercuda_amd.experiments import NextFrameDenoiser  # noqa: E402
 
 W, H = (int(os.environ.get("PROBE_W", 3840)), int(os.environ.get("PROBE_H", 2160)))
 FRAMES, WARM, NSEQ = int(os.environ.get("PROBE_FRAMES", 40)), 8, 12
@@ -19,7 +20,7 @@ seq = [rmd.svgf.synth_gbuffer(W, H, f) for f in range(NSEQ)]
 
 
 def run(ahead, frames, outs=None):
-    den = rmd.SvgfDenoiser(W, H, params=p)
+    den = NextFrameDenoiser(W, H, params=p)
     out = torch.empty_like(seq[0][0])
     t0 = None
     for f in range(WARM + frames):
