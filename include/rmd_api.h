@@ -87,7 +87,8 @@ int rmd_filter_baseline(rmd_gbuffer frame, rmd_filter_params params, void* strea
  * output is corrupted by a stride mismatch, SURVEY §0.2, and is not a parity target).
  * params.type selects AVERAGE (reference behaviour) or the modes the reference declares but never
  * implements (include/filter.cuh:12-19; every kernel there uses w = 1):
- *   GAUSSIAN  w = exp(-(dx^2+dy^2)/(2 sigmaSpace^2)) over the (2r+1)^2 window
+ *   GAUSSIAN  w = exp(-(dx^2+dy^2)/(2 sigmaSpace^2)) over the (2r+1)^2 window; radius <= 12 (the separable kernel's LDS tile;
+ *             RMD_E_PARAM beyond -- AVERAGE takes any radius, as the reference does)
  *   CROSS     GAUSSIAN x exp(-|dc|^2/(2 sigmaColor^2)) x exp(-|da|^2/(2 sigmaAlbedo^2)) x
  *             exp(-|dn|^2/(2 sigmaNormal^2)) with c = the level's input plane, a / n = frame.albedo /
  *             frame.normal (0..255 units; a term with sigma <= 0 or a NULL plane is dropped)
@@ -431,7 +432,8 @@ int  rmd_stream_wait_event(void* stream, void* event);
    of this package gains nothing from it (its six launches are queued ahead of the GPU anyway: 1080p 0.276 / 0.287 ms per
    frame replayed against 0.287 / 0.271 eager in two runs, 4K 0.877 against 0.874, tools/graph_probe.py).  The graph holds
    the POINTERS of the captured calls: capture an even number of frames of an rmd_svgf_context / SvgfDenoiser (its history
-   planes ping-pong) and keep the input planes in place.
+   planes ping-pong) and keep the input planes in place; it also bakes in whether a frame had a history and the
+   parameters: no rmd_svgf_context_reset_history and no other rmd_svgf_params between capture and replay.
    `stream` must be a created stream, not NULL (the legacy default stream cannot be captured). */
 int  rmd_graph_capture_begin(void* stream);
 int  rmd_graph_capture_end(void* stream, void** graph);     /* ends the capture, instantiates; on failure the capture is ended and *graph = NULL */

@@ -67,6 +67,20 @@ public:
     FrameGraph(const FrameGraph&) = delete;
     FrameGraph& operator=(const FrameGraph&) = delete;
     ~FrameGraph() { rmd_graph_destroy(exec); }
+    // RAII capture: everything queued on `stream` while a Capture lives is recorded; commit() ends the capture and instantiates
+    // the graph, and a Capture that goes out of scope without it (an exception between begin and end) ends and DISCARDS the
+    // capture instead of leaving the stream in capture mode.
+    class Capture {
+        FrameGraph& g; void* stream; bool open = true;
+    public:
+        Capture(FrameGraph& graph, void* s) : g(graph), stream(s) { rmdCheck(rmd_graph_capture_begin(stream), "FrameGraph::Capture"); }
+        Capture(const Capture&) = delete;
+        Capture& operator=(const Capture&) = delete;
+        void commit() { open = false; g.end(stream); }
+        ~Capture() { if (open) { void* dropped = nullptr; (void)rmd_graph_capture_end(stream, &dropped); rmd_graph_destroy(dropped); } }
+    };
+    // The graph holds what the captured calls decided when they were queued: plane pointers, whether the frame had a history (no
+    // resetHistory() between capture and replay), the parameters and band plans (the same SvgfParams).
     static void begin(void* stream) { rmdCheck(rmd_graph_capture_begin(stream), "FrameGraph::begin"); }
     void end(void* stream) { rmd_graph_destroy(exec); exec = nullptr; rmdCheck(rmd_graph_capture_end(stream, &exec), "FrameGraph::end"); }
     void launch(void* stream) { rmdCheck(rmd_graph_launch(exec, stream), "FrameGraph::launch"); }

@@ -110,8 +110,8 @@ void orc_weighted_filter(const uint8_t* render, uint8_t* denoised, uint8_t* buf0
              * horizontal sums H(x, y') = sum_dx g(dx) c(x+dx, y') for dx = -r..r inside the frame, then
              * out = [sum_dy g(dy) H(x, y+dy)] / (hw(x) * vw(y)) with hw, vw the sums of the in-frame g(dx), g(dy);
              * each accumulation one fused multiply-add (fmaf: a single rounding), the weight sums plain additions. */
-            float g[64];
-            for (int d = 0; d <= radius && d < 64; ++d) g[d] = expf(-(float)(d * d) * is_s);
+            float* g = (float*)malloc(sizeof(float) * (size_t)(radius + 1));      /* any radius (a fixed 64-entry table was read past its end) */
+            for (int d = 0; d <= radius; ++d) g[d] = expf(-(float)(d * d) * is_s);
             float* hrow = (float*)malloc(sizeof(float) * (size_t)W * (size_t)H * 3);
             for (int y = 0; y < H; ++y)
                 for (int x = 0; x < W; ++x) {
@@ -143,6 +143,7 @@ void orc_weighted_filter(const uint8_t* render, uint8_t* denoised, uint8_t* buf0
                     out[i] = (uint8_t)(sr / sw); out[i + 1] = (uint8_t)(sg / sw); out[i + 2] = (uint8_t)(sb / sw); out[i + 3] = 0;
                 }
             free(hrow);
+            free(g);
             continue;
         }
         for (int y = 0; y < H; ++y)

@@ -228,6 +228,100 @@ __global__ __launch_bounds__(256) void box_scan_kernel(const uchar4* __restrict_
     }
 }
 
+// ---- run kernel: radii 33 .. 127, cost independent of the radius per output row (the reference takes any radius,
+// src/filter.cu:34; (2r+1)^2 taps per pixel from global memory -- the direct kernel -- is 16 641 loads per pixel at r = 64) -----------
+// A WAVE owns 64 columns x a band of rows and needs nobody else: no barriers.
+//   - hsum(y): the 64 windows' row sums of row y.  The staged row is 64 + 2r <= 318 pixels, taken in chunks of 64 (one pixel per
+//     lane); per chunk a DPP inclusive scan per channel (32-bit fields) + the carry of the chunks before it give the row's prefix
+//     sums into the wave's LDS row; a window's sum is prefix[x + 2r + 1] - prefix[x].  Pixels outside the frame count 0.
+//   - V(y) = sum of hsum over rows y - r .. y + r: built once at the top of the band (2r + 1 rows), then a RUNNING sum:
+//     + hsum(y + r + 1) - hsum(y - r).  The leaving row is scanned again rather than kept (a ring of 2r + 1 row sums would be
+//     up to 200 KB per workgroup); both rows' chunks are fetched before either is scanned.
+//   - quotient: the reference's own (unsigned char)((float)s / (float)n) -- s < 2^24 for r <= 127, so the integer sum is exactly
+//     what its float accumulation holds, in any order.
+// Bit-exact like every other box kernel (tests/test_box_gpu.py: radii 33, 40, 64, 127).
+constexpr int kRunMaxChunks = 5;         // ceil((64 + 2 * 127) / 64)
+
+__device__ __forceinline__ void run_row_prefix(const unsigned* __restrict__ in32, const int W, const int H, const int gy, const int xs,
+                                               const int nchunks, const int lane, unsigned (&px)[kRunMaxChunks])
+{
+    const bool rowok = gy >= 0 && gy < H;                 // wave-uniform
+#pragma unroll
+    for (int c = 0; c < kRunMaxChunks; ++c) {
+        const int gx = xs + c * 64 + lane;
+        px[c] = (c < nchunks && rowok && gx >= 0 && gx < W) ? in32[(size_t)gy * W + gx] : 0u;
+    }
+}
+
+// prefix sums of one staged row into P[0 .. nchunks*64] (3 channels); then this lane's window sums
+template <bool GRAY>
+__device__ __forceinline__ void run_row_sums(const unsigned (&px)[kRunMaxChunks], const int nchunks, const int lane, const int radius,
+                                             uint4* P, unsigned& hr, unsigned& hg, unsigned& hb)
+{
+    unsigned cr = 0u, cg = 0u, cb = 0u;
+    if (lane == 0) P[0] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int c = 0; c < kRunMaxChunks; ++c) {
+        if (c >= nchunks) break;                          // wave-uniform
+        const unsigned r = px[c] & 0xffu, g = (px[c] >> 8) & 0xffu, b = (px[c] >> 16) & 0xffu;
+        const unsigned sr = wave_inclusive_scan(r) + cr;
+        unsigned sg = 0u, sb = 0u;
+        if (!GRAY) { sg = wave_inclusive_scan(g) + cg; sb = wave_inclusive_scan(b) + cb; }
+        P[c * 64 + lane + 1] = make_uint4(sr, sg, sb, 0u);
+        cr = (unsigned)__builtin_amdgcn_readlane((int)sr, 63);
+        if (!GRAY) { cg = (unsigned)__builtin_amdgcn_readlane((int)sg, 63); cb = (unsigned)__builtin_amdgcn_readlane((int)sb, 63); }
+    }
+    __builtin_amdgcn_wave_barrier();                      // (one wave's LDS accesses execute in order)
+    const uint4 hi = P[lane + 2 * radius + 1], lo = P[lane];
+    hr = hi.x - lo.x; hg = hi.y - lo.y; hb = hi.z - lo.z;
+    __builtin_amdgcn_wave_barrier();                      // before the next row overwrites P
+}
+
+template <bool GRAY>
+__global__ __launch_bounds__(256) void box_run_kernel(const uchar4* __restrict__ in, uchar4* __restrict__ out, int W, int H, int radius, int band_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char box_lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int L = 64 + 2 * radius, nchunks = (L + 63) / 64;
+    uint4* P = reinterpret_cast<uint4*>(box_lds) + (size_t)wave * (nchunks * 64 + 1);
+    const int x0 = blockIdx.x * 64, xs = x0 - radius;
+    const int yb = (blockIdx.y * 4 + wave) * band_rows;
+    if (yb >= H) return;
+    const int ye = min(H, yb + band_rows);
+    const unsigned* in32 = reinterpret_cast<const unsigned*>(in);
+    unsigned vr = 0u, vg = 0u, vb = 0u;
+    unsigned pa[kRunMaxChunks], pb[kRunMaxChunks];
+    for (int y = yb - radius; y <= yb + radius; ++y) {    // (rows outside the frame add 0 and cost one empty scan)
+        if (y < 0 || y >= H) continue;
+        unsigned hr, hg, hb;
+        run_row_prefix(in32, W, H, y, xs, nchunks, lane, pa);
+        run_row_sums<GRAY>(pa, nchunks, lane, radius, P, hr, hg, hb);
+        vr += hr; vg += hg; vb += hb;
+    }
+    const int gx = x0 + lane;
+    const int cntx = min(gx + radius, W - 1) - max(gx - radius, 0) + 1;
+    for (int y = yb; y < ye; ++y) {
+        if (gx < W) {
+            const int cnty = min(y + radius, H - 1) - max(y - radius, 0) + 1;
+            const float n = (float)(cntx * cnty);
+            uchar4 o;
+            const unsigned char qr = (unsigned char)((float)vr / n);
+            if (GRAY) o = make_uchar4(qr, qr, qr, 0);
+            else o = make_uchar4(qr, (unsigned char)((float)vg / n), (unsigned char)((float)vb / n), 0);
+            out[(size_t)y * W + gx] = o;
+        }
+        if (y + 1 < ye) {
+            const int yin = y + radius + 1, yout = y - radius;
+            run_row_prefix(in32, W, H, yin, xs, nchunks, lane, pa);
+            run_row_prefix(in32, W, H, yout, xs, nchunks, lane, pb);
+            unsigned hr, hg, hb;
+            if (yin < H) { run_row_sums<GRAY>(pa, nchunks, lane, radius, P, hr, hg, hb); vr += hr; vg += hg; vb += hb; }
+            if (yout >= 0) { run_row_sums<GRAY>(pb, nchunks, lane, radius, P, hr, hg, hb); vr -= hr; vg -= hg; vb -= hb; }
+        }
+    }
+}
+
 static int box_scan_rows(int) { return 32; }
 static size_t box_scan_lds_bytes(int radius)
 {
@@ -454,7 +548,7 @@ static int validate(const rmd_gbuffer& f, const rmd_filter_params& p, const char
 
 // One launch per level with the reference's plane routing (src/filter.cu:24-25).
 template <bool GRAY>
-static int run_levels(const rmd_gbuffer& f, const rmd_filter_params& p, bool use_lds, hipStream_t stream)
+static int run_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStream_t stream)
 {
     const int W = f.shape.x, H = f.shape.y;
     for (int level = 0; level < p.depth; ++level) {
@@ -470,12 +564,25 @@ static int run_levels(const rmd_gbuffer& f, const rmd_filter_params& p, bool use
             if (rows == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(box_scan_kernel<GRAY, 64>), grid, dim3(256), box_scan_lds_bytes(p.radius), stream, in, out, W, H, p.radius);
             else            hipLaunchKernelGGL(HIP_KERNEL_NAME(box_scan_kernel<GRAY, 32>), grid, dim3(256), box_scan_lds_bytes(p.radius), stream, in, out, W, H, p.radius);
 #ifdef RMD_EXPERIMENTS
-        } else if (use_lds) {               // (reached with RMD_BOX_SCAN=0 only: the scan kernel takes every radius this one can)
+        } else if (scan_off && p.cacheInput && p.radius <= kMaxExactRadius && box_lds_bytes(p.radius) <= 64 * 1024) {
+            // (RMD_BOX_SCAN=0 only: the 64 x 16 tile + halo kernel the scan kernel replaced)
             dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + kTileY - 1) / kTileY);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(box_lds_kernel<GRAY>), grid, dim3(256), box_lds_bytes(p.radius), stream,
                                in, out, W, H, p.radius);
 #endif
+        } else if (p.radius > kScanMaxRadius && p.radius <= kMaxExactRadius) {
+            // radii 33 .. 127: running sums, a wave per 64 columns x band.  Bands of ~4r rows (the 2r + 1 rows that start a
+            // band's sum are its overhead), fewer when that would leave CUs idle.
+            const int strips = (W + 63) / 64;
+            int band = 4 * p.radius;
+            while (band > 16 && (long long)strips * ((H + band - 1) / band) < 4LL * 4 * device_cus()) band /= 2;
+            const int nchunks = (64 + 2 * p.radius + 63) / 64;
+            dim3 grid(strips, ((H + band - 1) / band + 3) / 4);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(box_run_kernel<GRAY>), grid, dim3(256), 4 * (nchunks * 64 + 1) * sizeof(uint4), stream,
+                               in, out, W, H, p.radius, band);
         } else {
+            // radius 0, and radii >= 128: there the reference's float accumulation rounds (sums reach 2^24), so its tap ORDER is
+            // part of the result and only the kernel that follows it reproduces it
             dim3 grid((W + kBoxBlockX - 1) / kBoxBlockX, (H + kBoxBlockY - 1) / kBoxBlockY);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(box_direct_kernel<GRAY>), grid, dim3(256), 0, stream, in, out, W, H, p.radius);
         }
@@ -494,7 +601,7 @@ int rmd_filter_baseline(rmd_gbuffer frame, rmd_filter_params params, void* strea
 {
     if (int e = validate(frame, params, "rmd_filter_baseline")) return e;
     // The reference baseline ignores params.type (only AVERAGE exists, src/filter.cu:41).
-    return run_levels<true>(frame, params, /*use_lds=*/false, as_stream(stream));
+    return run_levels<true>(frame, params, as_stream(stream));
 }
 
 int rmd_filter_tiled(rmd_gbuffer frame, rmd_filter_params params, void* stream)
@@ -502,8 +609,9 @@ int rmd_filter_tiled(rmd_gbuffer frame, rmd_filter_params params, void* stream)
     if (int e = validate(frame, params, "rmd_filter_tiled")) return e;
     if (params.type != RMD_FILTER_AVERAGE)     // GAUSSIAN / CROSS / WAVELET: csrc/weighted_filter.hip
         return run_weighted_levels(frame, params, as_stream(stream));
-    const bool lds_ok = params.radius <= kMaxExactRadius && box_lds_bytes(params.radius) <= 64 * 1024;
-    return run_levels<false>(frame, params, params.cacheInput && lds_ok, as_stream(stream));
+    // cacheInput selects nothing: every kernel stages what it needs, and both settings give the reference's cacheInput = false
+    // result (its cached path is broken)
+    return run_levels<false>(frame, params, as_stream(stream));
 }
 
 }  // extern "C"

@@ -1218,6 +1218,7 @@ int rmd::launch_atrous(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
     a.b_row0 = two ? row0b : 0; a.b_row1 = two ? row1b : 0;
     a.b_band_h = a.b_band_base = a.b_nblocks = a.b_n_hi = a.b_band_h_hi = a.b_nblocks_hi = 0;
     a.nt_out = (double)(row1 - row0 + (two ? row1b - row0b : 0)) * f->width * 48.0 > 256.0e6 ? 1 : 0;
+    a.nt_out = tuning_env("RMD_NT_OUT", a.nt_out);          // (A/B knob of tools/boundary_probe.py; experiments build only)
     a.albedo8 = g8 ? g8->albedo : nullptr; a.out8 = g8 ? g8->denoised : nullptr;
 #ifdef RMD_EXPERIMENTS
     a.side_units = 0; a.side_every = 1; a.side_counter = nullptr;

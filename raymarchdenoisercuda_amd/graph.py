@@ -6,8 +6,12 @@
         den.denoise(*frame_b, out=out)
     g.launch()                              # on `stream`; the planes the captured calls named must still be alive and in place
 
-The first eager frame on a device sets kernel attributes and must have run before a capture."""
+The first eager frame on a device sets kernel attributes and must have run before a capture.  A graph bakes in what the captured
+calls decided when they were queued -- the plane POINTERS, whether the frame had a history (so: no reset_history() between
+capture and replay, and capture behind at least one eager frame), the parameters and the band plans (so: the same
+rmd_svgf_params, atrous_cus included)."""
 import ctypes as C
+import sys
 
 import torch
 
@@ -30,9 +34,11 @@ class Graph:
             self._h = None
 
     def __del__(self):
+        if sys.is_finalizing():            # the HIP runtime may already be gone: a crash in there cannot be caught
+            return
         try:
             self.destroy()
-        except Exception:       # interpreter shutdown
+        except Exception:
             pass
 
 

@@ -394,9 +394,15 @@ TEST(FRAME_GRAPH)
         pair(ctx, got.data());                             // eager: kernel attributes set, history valid
         rmdCheck(rmd_stream_sync(stream), "sync");
         FrameGraph graph;
-        FrameGraph::begin(stream);
-        pair(ctx, got.data());                             // captured, not run
-        graph.end(stream);
+        try {                                              // a capture abandoned by an exception leaves the stream usable
+            FrameGraph::Capture scope(graph, stream);
+            throw std::runtime_error("host code failed between begin and end");
+        } catch (const std::runtime_error&) {}
+        {
+            FrameGraph::Capture scope(graph, stream);
+            pair(ctx, got.data());                         // captured, not run
+            scope.commit();
+        }
         for (int k = 0; k < 3; ++k) graph.launch(stream);
         rmdCheck(rmd_stream_sync(stream), "sync");
     }

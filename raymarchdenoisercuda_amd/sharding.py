@@ -186,6 +186,16 @@ def halo_bytes(plan: StripPlan, width):
     return total
 
 
+class _NoExchange:
+    """Exchange hooks that exchange nothing (ShardedDenoiser(timing_only_no_exchange=True))."""
+
+    def mid_ready(self, plane):
+        pass
+
+    def mid_wait(self):
+        pass
+
+
 class ShardedDenoiser:
     """Per-rank driver: strip plan + SvgfDenoiser + the neighbour exchanges of a frame.
 
@@ -200,7 +210,8 @@ class ShardedDenoiser:
     halo completed lazily on the T+V stream); it does not support exchange_iteration.
     """
 
-    def __init__(self, width, height, params=None, device="cuda", group=None, rank=None, world=None, pipelined=False):
+    def __init__(self, width, height, params=None, device="cuda", group=None, rank=None, world=None, pipelined=False,
+                 timing_only_no_exchange=False):
         from . import svgf  # needs librmd.so; the plan/exchange helpers above do not
         self.svgf = svgf
         self.group = group
@@ -212,6 +223,9 @@ class ShardedDenoiser:
         self.den = svgf.SvgfDenoiser(width, height, self.plan.buf_row0, self.plan.buf_rows, self.params, device,
                                      pipelined=pipelined)
         self.exchange = self.world > 1 and dist.is_initialized()
+        # tools/strip_probe.py: what ONE rank's launches cost without a process group -- the halo rows are never delivered, the
+        # outputs are not a frame; SvgfDenoiser.denoise refuses that unless it is told so through (empty) exchange hooks
+        self.timing_only = bool(timing_only_no_exchange) and not self.exchange
         self.pipelined = pipelined
         self._halo_pending = False
         self._hist_done = self._mid_done = None
@@ -274,7 +288,8 @@ class ShardedDenoiser:
     def denoise(self, color, nd, motion, out=None):
         """Strip rows [row0,row1) of `out` (valid after synchronize())."""
         if not self.exchange:
-            return self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1)
+            hooks = _NoExchange() if self.timing_only and self.plan.mid_iteration >= 0 else None
+            return self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1, hooks=hooks)
         if self.pipelined:
             out = self.den.denoise(color, nd, motion, out, self.plan.row0, self.plan.row1, before_tv=self._complete_halo)
             self._halo_pending = True
@@ -285,3 +300,9 @@ class ShardedDenoiser:
         self.den.synchronize()
         if self.comm_stream is not None:
             self.comm_stream.synchronize()
+
+    def reset_history(self):
+        """The next frame is a first frame again (every rank must call it at the same point of the sequence)."""
+        self.synchronize()
+        self.den.reset_history()
+        self._halo_pending = False

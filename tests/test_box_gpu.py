@@ -65,7 +65,7 @@ def test_stream_kernel_radii_and_ragged_strips(rmd, orc, cuda, shape, r):
 @pytest.mark.parametrize("shape", [(70, 61), (100, 200), (33, 130)])
 def test_scan_kernel_radii(rmd, orc, cuda, shape, r):
     """Radii 1..32 outside the stream kernel's reach (here: widths that are not multiples of 4, or radius > 4) run prefix sums
-    along the rows and running sums down the columns; 33 falls back to the LDS / direct kernels.  A saturated frame makes
+    along the rows and running sums down the columns; 33 is the first radius of the run kernel.  A saturated frame makes
     the largest sums the packed 16-bit prefix fields and the reciprocal division have to carry; bit-exact either way."""
     rng = np.random.default_rng(7 * r + shape[1])
     for img in (rng.integers(0, 256, shape + (4,), dtype=np.uint8), np.full(shape + (4,), 255, np.uint8)):
@@ -73,6 +73,32 @@ def test_scan_kernel_radii(rmd, orc, cuda, shape, r):
             got = run_gpu(rmd, img, r, 1, tiled, cache)
             want = orc.box_filter(img, r, 1, gray_from_r=not tiled)
             assert (got == want).all(), (shape, r, tiled, cache, np.argwhere(got != want)[:4])
+
+
+@pytest.mark.parametrize("r", [33, 40, 64, 100, 127, 128, 140])
+@pytest.mark.parametrize("shape", [(70, 61), (300, 200), (260, 515)])
+def test_run_kernel_radii(rmd, orc, cuda, shape, r):
+    """Radii 33 .. 127 (the reference takes any radius, src/filter.cu:34) run box_run_kernel: chunked prefix sums along the
+    rows, a running sum down a wave's band of rows, the reference's own float division.  Window sums stay below 2^24 there, so
+    they equal the reference's float accumulation in any order; from radius 128 on they do not, and the direct kernel, which
+    follows the reference's tap order, takes over (128, 140 here).  Windows larger than the frame, ragged strips, saturated
+    frames (the largest sums); bit-exact."""
+    rng = np.random.default_rng(3 * r + shape[1])
+    for img in (rng.integers(0, 256, shape + (4,), dtype=np.uint8), np.full(shape + (4,), 255, np.uint8)):
+        for tiled, cache in ((True, True), (False, False)):
+            got = run_gpu(rmd, img, r, 1, tiled, cache)
+            want = orc.box_filter(img, r, 1, gray_from_r=not tiled, threads=8)
+            assert (got == want).all(), (shape, r, tiled, cache, np.argwhere(got != want)[:4])
+
+
+def test_run_kernel_on_a_wide_frame(rmd, orc, cuda):
+    """Radius 64 on half of the reference's bench shape (1920 x 540): many bands per column strip, 30 strips; against the oracle
+    on all host threads."""
+    rng = np.random.default_rng(64)
+    img = rng.integers(0, 256, (540, 1920, 4), dtype=np.uint8)
+    got = run_gpu(rmd, img, 64, 1, True, True)
+    want = orc.box_filter(img, 64, 1, gray_from_r=False, threads=16)
+    assert (got == want).all()
 
 
 @pytest.mark.parametrize("tiled", [False, True])

@@ -47,7 +47,8 @@ print(f"7680x4320 frame, one GPU      : {ms1:.4f} ms/frame  {W * H / ms1 / 1e3:.
 for X in [int(v) for v in os.environ.get("PROBE_EXCHANGE", "-1 3").split()]:
     p.exchange_iteration = X
     for R in RANKS:
-        sd = sharding.ShardedDenoiser(W, H, params=p, rank=R, world=N, pipelined=os.environ.get("PROBE_PIPELINE", "0") == "1")
+        sd = sharding.ShardedDenoiser(W, H, params=p, rank=R, world=N, pipelined=os.environ.get("PROBE_PIPELINE", "0") == "1",
+                                      timing_only_no_exchange=True)
         seq = [sd.synth(f) for f in range(WARM + FRAMES)]
         msn = run(sd.denoise, seq, sd.synchronize)
         pl = sd.plan
