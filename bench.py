@@ -33,8 +33,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 ATROUS_BYTES_PER_PX = 48       # per iteration: color 16 + nd 16 read, color 16 written
 FULL_BYTES_PER_PX = 424        # T 120 + V 64 + 5 x 48, every pass priced on its own
-MOVED_BYTES_PER_PX = 360       # what rmd_svgf_frame moves: T+V 88 read + 32 written (v_color, t_moments; V's windows are recomputed
-                               # in the T workgroup, no t_color plane), 5 x 48
+MOVED_BYTES_PER_PX = 346       # what rmd_svgf_frame moves: T+V 81 read (color 16, nd 16, motion 8, prev_nd 16, hist_color 16, hist_moments 8,
+                               # hist_len 1) + 25 written (v_color 16, t_moments 8, t_len 1; V's windows are recomputed in the T
+                               # workgroup, no t_color plane), 5 x 48
 MAX_RESIDENT = 64              # pre-generated G-buffer frames kept in HBM
 
 
@@ -406,7 +407,7 @@ def cpu_baseline():
             orc.frame(fr, p, threads=threads if f > 0 else cores)
             if f > 0:
                 dt += time.perf_counter() - t0
-            hc, hm, pn = fr.hist_color_out, fr.t_moments, fr.nd
+            hc, hm, pn = fr.history()
         return (frames - 1) * w * h / dt / 1e6, dt
 
     v4k, dt4k = timed(3840, 2160, 3, cores)

@@ -123,7 +123,7 @@ typedef struct rmd_svgf_params {
     /* T: temporal reprojection + accumulation */
     float alpha_color;      /* 0.05  minimum blend weight of the new colour sample             */
     float alpha_moments;    /* 0.2   minimum blend weight of the new luminance moments         */
-    int   h_max;            /* 32    history length clamp                                      */
+    int   h_max;            /* 32    history length clamp, 1 .. 255 (the history length plane is uint8) */
     float k_z;              /* 10    depth-consistency slope factor                            */
     float k_n;              /* 0.9   normal-consistency cosine threshold                       */
     int   max_motion_rows;  /* 64    history taps with |tap.y - y| > this are invalid; makes the
@@ -175,13 +175,17 @@ typedef struct rmd_svgf_frame_desc {
     const float* motion;       /* float2 pixels, current -> previous                            */
     /* history (previous frame) */
     const float* hist_color;   /* float4 rgb + variance                                         */
-    const float* hist_moments; /* float4 (m1, m2, history length, 0)                            */
+    const float* hist_moments; /* float2 (m1, m2): first and second luminance moment, 8-byte aligned       */
+    const unsigned char* hist_len; /* uint8 history length h (1 .. h_max <= 255), one byte per pixel.  The moments used to
+                                  be a float4 (m1, m2, h, 0): 16 B/px read per reprojection tap and 16 written, of which 9 carry
+                                  anything -- the temporal pass is HBM-bound and moved 120 B/px, now 106              */
     const float* prev_nd;      /* float4                                                        */
     /* intermediates / outputs */
     float* t_color;            /* T out: float4 (c', variance).  rmd_svgf_frame / rmd_svgf_frame_tv with v_tile_flags set
                                   treat it as scratch: only the 64x4 tiles T flags for V are written (v_color holds
                                   T's output for every pixel); rmd_svgf_temporal always writes all of it            */
-    float* t_moments;          /* T out: float4 (m1', m2', h, 0) -> next frame's hist_moments   */
+    float* t_moments;          /* T out: float2 (m1', m2') -> next frame's hist_moments         */
+    unsigned char* t_len;      /* T out: uint8 h -> next frame's hist_len                       */
     int*   t_debug;            /* optional int4 (q0.x, q0.y, tap mask, h): the bit-exact outputs */
     float* v_color;            /* V out: float4                                                 */
     float* hist_color_out;     /* A out of iteration `hist_iteration` -> next frame's hist_color */
@@ -316,7 +320,7 @@ int  rmd_svgf_gbuffer_frame(rmd_gbuffer frame, rmd_svgf_context* ctx, const rmd_
  * fills: the bit-exact outputs, for tests.  NULL switches it off. */
 int  rmd_svgf_context_set_debug_plane(rmd_svgf_context* ctx, int* t_debug);
 /* The history planes the NEXT rmd_svgf_context_denoise call will read (for halo exchange). */
-int  rmd_svgf_context_history(rmd_svgf_context* ctx, float** hist_color, float** hist_moments);
+int  rmd_svgf_context_history(rmd_svgf_context* ctx, float** hist_color, float** hist_moments, unsigned char** hist_len);
 /* Fill a descriptor with the context's planes for the next frame (advanced use / tests). */
 int  rmd_svgf_context_describe(rmd_svgf_context* ctx, rmd_svgf_frame_desc* f);
 
@@ -334,11 +338,12 @@ typedef struct rmd_strip_plan {
     int mid_iteration, mid_rows;  /* rmd_svgf_frame_mid_exchange(): the a-trous iteration whose output crosses ranks inside
                                      a frame (-1 = none) and the rows per side that travel                  */
 } rmd_strip_plan;
-enum { RMD_HALO_RECV = 0, RMD_HALO_SEND = 1, RMD_HALO_MAX_STEPS = 8 };
-enum { RMD_PLANE_HIST_COLOR = 0, RMD_PLANE_HIST_MOMENTS = 1, RMD_PLANE_MID = 2 };
+enum { RMD_HALO_RECV = 0, RMD_HALO_SEND = 1, RMD_HALO_MAX_STEPS = 12 };
+/* planes a halo step may name, and their bytes per pixel: 16 (float4), 8 (float2), 16 (float4), 1 (uint8) */
+enum { RMD_PLANE_HIST_COLOR = 0, RMD_PLANE_HIST_MOMENTS = 1, RMD_PLANE_MID = 2, RMD_PLANE_HIST_LEN = 3, RMD_PLANE_COUNT = 4 };
 typedef struct rmd_halo_step {
     int kind;                  /* RMD_HALO_RECV | RMD_HALO_SEND                                      */
-    int plane;                 /* RMD_PLANE_HIST_COLOR | RMD_PLANE_HIST_MOMENTS | RMD_PLANE_MID        */
+    int plane;                 /* RMD_PLANE_HIST_COLOR | RMD_PLANE_HIST_MOMENTS | RMD_PLANE_HIST_LEN | RMD_PLANE_MID   */
     int row_lo, row_hi;        /* GLOBAL rows [row_lo,row_hi)                                        */
     int peer;                  /* rank - 1 or rank + 1                                               */
 } rmd_halo_step;
@@ -364,13 +369,15 @@ int rmd_comm_create(const void* id128, int world, int rank, rmd_comm** out);
 int rmd_comm_create_all(int ndev, const int* devices /* NULL = 0..ndev-1 */, rmd_comm** out);
 int rmd_comm_destroy(rmd_comm* c);
 /* The per-frame history halo exchange of this rank: ncclGroupStart; ncclSend / ncclRecv(rank +- 1) of
- * the rmd_halo_plan rows; ncclGroupEnd -- asynchronous on `stream`.  Call it between frame k's
+ * the rmd_halo_plan rows (the rows named for RMD_PLANE_HIST_MOMENTS travel for RMD_PLANE_HIST_LEN as well: the plan lists
+ * both); ncclGroupEnd -- asynchronous on `stream`.  Call it between frame k's
  * hist_iteration and frame k+1's temporal pass, on the planes rmd_svgf_context_history returns.
  * world == 1 (or an empty plan) is a no-op and needs no communicator. */
-int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* hist_color, float* hist_moments, void* stream);
+int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* hist_color, float* hist_moments,
+                      unsigned char* hist_len, void* stream);
 /* Single-process form: plans[k], planes and stream of rank k for k < world, all ranks in one group. */
 int rmd_halo_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* hist_color,
-                          float* const* hist_moments, void* const* streams);
+                          float* const* hist_moments, unsigned char* const* hist_len, void* const* streams);
 /* The mid-frame exchange (rmd_mid_halo_plan) of iteration X's output plane -- rmd_svgf_context_mid_plane /
  * rmd_svgf_frame_iteration_plane -- between RMD_ATROUS_HEAD and RMD_ATROUS_TAIL, asynchronous on `stream` (a second
  * stream, so that RMD_ATROUS_INTERIOR runs meanwhile). */
@@ -378,11 +385,11 @@ int rmd_mid_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* 
 int rmd_mid_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* mid_planes, void* const* streams);
 /* Explicit steps on communicator comm_index of c (tests: a loop-back exchange on one GPU). */
 int rmd_halo_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
-                            int width, float* hist_color, float* hist_moments, void* stream);
-/* The same with all three planes a step may name: planes[RMD_PLANE_HIST_COLOR], [RMD_PLANE_HIST_MOMENTS], [RMD_PLANE_MID]
- * (entries no step names may be NULL). */
+                            int width, float* hist_color, float* hist_moments, unsigned char* hist_len, void* stream);
+/* The same with all planes a step may name: planes[RMD_PLANE_HIST_COLOR], [RMD_PLANE_HIST_MOMENTS], [RMD_PLANE_MID],
+ * [RMD_PLANE_HIST_LEN] (entries no step names may be NULL). */
 int rmd_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
-                       int width, float* const planes[3], void* stream);
+                       int width, void* const planes[RMD_PLANE_COUNT], void* stream);
 
 /* ---- 8-bit <-> float plane conversion --------------------------------- */
 /* uchar4 -> float4, c/255; optional per-pixel renormalisation of xyz (for normals). */

@@ -165,12 +165,13 @@ public:
         }
         if (world == 1) return;
         std::vector<float*> hc(world), hm(world);
-        for (int k = 0; k < world; ++k) rmdCheck(rmd_svgf_context_history(ranks[k].ctx->get(), &hc[k], &hm[k]), "NodeDenoiser(history)");
+        std::vector<unsigned char*> hl(world);
+        for (int k = 0; k < world; ++k) rmdCheck(rmd_svgf_context_history(ranks[k].ctx->get(), &hc[k], &hm[k], &hl[k]), "NodeDenoiser(history)");
         if (comm_.get()) {
             std::vector<rmd_strip_plan> plans(world);
             std::vector<void*> streams(world);
             for (int k = 0; k < world; ++k) { plans[k] = ranks[k].plan; streams[k] = ranks[k].stream; }
-            rmdCheck(rmd_halo_exchange_all(comm_.get(), plans.data(), width_, hc.data(), hm.data(), streams.data()), "NodeDenoiser(exchange)");
+            rmdCheck(rmd_halo_exchange_all(comm_.get(), plans.data(), width_, hc.data(), hm.data(), hl.data(), streams.data()), "NodeDenoiser(exchange)");
             return;
         }
         // ranks share a device (rehearsal): the same plan, rows copied device to device once every strip is done
@@ -179,9 +180,12 @@ public:
             for (const rmd_halo_step& s : ranks[k].plan.haloSteps()) {
                 if (s.kind != RMD_HALO_RECV) continue;
                 const Rank& q = ranks[s.peer];
-                float* dst = (s.plane == 0 ? hc[k] : hm[k]) + (size_t)(s.row_lo - ranks[k].plan.buf_row0) * width_ * 4;
-                const float* src = (s.plane == 0 ? hc[s.peer] : hm[s.peer]) + (size_t)(s.row_lo - q.plan.buf_row0) * width_ * 4;
-                rmdCheck(rmd_memcpy_d2d(dst, src, (size_t)(s.row_hi - s.row_lo) * width_ * 16, ranks[k].stream), "NodeDenoiser(copy)");
+                // hist_color float4, hist_moments float2, hist_len uint8 (include/rmd_api.h RMD_PLANE_*)
+                const size_t px = s.plane == RMD_PLANE_HIST_COLOR ? 16 : s.plane == RMD_PLANE_HIST_MOMENTS ? 8 : 1;
+                auto base = [&](int rank) { return s.plane == RMD_PLANE_HIST_COLOR ? (unsigned char*)hc[rank] : s.plane == RMD_PLANE_HIST_MOMENTS ? (unsigned char*)hm[rank] : hl[rank]; };
+                unsigned char* dst = base(k) + (size_t)(s.row_lo - ranks[k].plan.buf_row0) * width_ * px;
+                const unsigned char* src = base(s.peer) + (size_t)(s.row_lo - q.plan.buf_row0) * width_ * px;
+                rmdCheck(rmd_memcpy_d2d(dst, src, (size_t)(s.row_hi - s.row_lo) * width_ * px, ranks[k].stream), "NodeDenoiser(copy)");
             }
     }
     void synchronize()

@@ -44,8 +44,10 @@ const char* orc_abi_layout(void)
     FIELD(rmd_svgf_frame_desc, width, "i"); FIELD(rmd_svgf_frame_desc, height, "i");
     FIELD(rmd_svgf_frame_desc, buf_row0, "i"); FIELD(rmd_svgf_frame_desc, buf_rows, "i");
     FIELD(rmd_svgf_frame_desc, color, "p"); FIELD(rmd_svgf_frame_desc, nd, "p"); FIELD(rmd_svgf_frame_desc, motion, "p");
-    FIELD(rmd_svgf_frame_desc, hist_color, "p"); FIELD(rmd_svgf_frame_desc, hist_moments, "p"); FIELD(rmd_svgf_frame_desc, prev_nd, "p");
-    FIELD(rmd_svgf_frame_desc, t_color, "p"); FIELD(rmd_svgf_frame_desc, t_moments, "p"); FIELD(rmd_svgf_frame_desc, t_debug, "p");
+    FIELD(rmd_svgf_frame_desc, hist_color, "p"); FIELD(rmd_svgf_frame_desc, hist_moments, "p"); FIELD(rmd_svgf_frame_desc, hist_len, "p");
+    FIELD(rmd_svgf_frame_desc, prev_nd, "p");
+    FIELD(rmd_svgf_frame_desc, t_color, "p"); FIELD(rmd_svgf_frame_desc, t_moments, "p"); FIELD(rmd_svgf_frame_desc, t_len, "p");
+    FIELD(rmd_svgf_frame_desc, t_debug, "p");
     FIELD(rmd_svgf_frame_desc, v_color, "p"); FIELD(rmd_svgf_frame_desc, hist_color_out, "p"); FIELD(rmd_svgf_frame_desc, ping, "p");
     FIELD(rmd_svgf_frame_desc, out_color, "p"); FIELD(rmd_svgf_frame_desc, stats, "p"); FIELD(rmd_svgf_frame_desc, v_tile_flags, "p");
     BEGIN(rmd_strip_plan);

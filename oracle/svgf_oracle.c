@@ -20,6 +20,7 @@
 
 #define PIX4(plane, f, x, y) ((plane) + (((size_t)((y) - (f)->buf_row0)) * (size_t)(f)->width + (size_t)(x)) * 4)
 #define PIX2(plane, f, x, y) ((plane) + (((size_t)((y) - (f)->buf_row0)) * (size_t)(f)->width + (size_t)(x)) * 2)
+#define PIX1(plane, f, x, y) ((plane) + (((size_t)((y) - (f)->buf_row0)) * (size_t)(f)->width + (size_t)(x)))
 
 static inline float lum3(const float* c) { return 0.2126f * c[0] + 0.7152f * c[1] + 0.0722f * c[2]; }
 static inline float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -82,12 +83,13 @@ void orc_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
                 if (!ok_n) continue;
                 mask |= 1 << k;
                 const float* hc = PIX4(f->hist_color, f, tx, ty);
-                const float* hm = PIX4(f->hist_moments, f, tx, ty);
+                const float* hm = PIX2(f->hist_moments, f, tx, ty);      /* float2 (m1, m2) */
+                const uint8_t* hl = PIX1(f->hist_len, f, tx, ty);        /* uint8 history length */
                 float w = wk[k];
                 wsum += w;
                 pc[0] += w * hc[0]; pc[1] += w * hc[1]; pc[2] += w * hc[2];
                 pm1 += w * hm[0]; pm2 += w * hm[1];
-                if (w > best_w) { best_w = w; best_h = (int)hm[2]; }
+                if (w > best_w) { best_w = w; best_h = (int)hl[0]; }
             }
             /* A.T.3 */
             int h;
@@ -106,10 +108,11 @@ void orc_svgf_temporal(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
             float m1 = lerpf(pm1, l, a_m), m2 = lerpf(pm2, l * l, a_m);
             float var = m2 - m1 * m1; if (!(var > 0.0f)) var = 0.0f;
             float* oc = PIX4(f->t_color, f, x, y);
-            float* om = PIX4(f->t_moments, f, x, y);
+            float* om = PIX2(f->t_moments, f, x, y);
             oc[0] = lerpf(pc[0], c[0], a_c); oc[1] = lerpf(pc[1], c[1], a_c); oc[2] = lerpf(pc[2], c[2], a_c);
             oc[3] = var;
-            om[0] = m1; om[1] = m2; om[2] = (float)h; om[3] = 0.0f;
+            om[0] = m1; om[1] = m2;
+            *(uint8_t*)PIX1(f->t_len, f, x, y) = (uint8_t)h;          /* 1 <= h <= h_max <= 255 */
             if (f->t_debug) {
                 int* od = f->t_debug + (((size_t)(y - f->buf_row0)) * (size_t)W + (size_t)x) * 4;
                 od[0] = q0x; od[1] = q0y; od[2] = mask; od[3] = h;
@@ -125,9 +128,8 @@ void orc_svgf_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p, i
     for (int y = row0; y < row1; ++y) {
         for (int x = 0; x < W; ++x) {
             const float* c = PIX4(f->t_color, f, x, y);
-            const float* mo = PIX4(f->t_moments, f, x, y);
             float* o = PIX4(f->v_color, f, x, y);
-            int h = (int)mo[2];
+            int h = (int)*PIX1(f->t_len, f, x, y);
             if (h >= p->var_h_threshold) { o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3]; continue; }
             const float* nd = PIX4(f->nd, f, x, y);
             float gz = depth_gradient(f, f->nd, x, y);

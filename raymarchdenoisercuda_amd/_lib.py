@@ -61,8 +61,8 @@ class SvgfParams(C.Structure):
 class SvgfFrameDesc(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("buf_row0", C.c_int), ("buf_rows", C.c_int),
                 ("color", C.c_void_p), ("nd", C.c_void_p), ("motion", C.c_void_p),
-                ("hist_color", C.c_void_p), ("hist_moments", C.c_void_p), ("prev_nd", C.c_void_p),
-                ("t_color", C.c_void_p), ("t_moments", C.c_void_p), ("t_debug", C.c_void_p),
+                ("hist_color", C.c_void_p), ("hist_moments", C.c_void_p), ("hist_len", C.c_void_p), ("prev_nd", C.c_void_p),
+                ("t_color", C.c_void_p), ("t_moments", C.c_void_p), ("t_len", C.c_void_p), ("t_debug", C.c_void_p),
                 ("v_color", C.c_void_p), ("hist_color_out", C.c_void_p), ("ping", C.c_void_p * 2),
                 ("out_color", C.c_void_p), ("stats", C.c_void_p), ("v_tile_flags", C.c_void_p)]
 
@@ -76,7 +76,7 @@ class StripPlan(C.Structure):
 
 class HaloStep(C.Structure):
     RECV, SEND = 0, 1
-    PLANE_HIST_COLOR, PLANE_HIST_MOMENTS, PLANE_MID = 0, 1, 2
+    PLANE_HIST_COLOR, PLANE_HIST_MOMENTS, PLANE_MID, PLANE_HIST_LEN = 0, 1, 2, 3
     _fields_ = [("kind", C.c_int), ("plane", C.c_int), ("row_lo", C.c_int), ("row_hi", C.c_int), ("peer", C.c_int)]
 
 
@@ -116,7 +116,7 @@ SYMBOLS = {
     "rmd_svgf_context_mid_plane": (C.c_int, [_P, C.POINTER(SvgfParams), C.POINTER(_P)]),
     "rmd_svgf_gbuffer_frame": (C.c_int, [GBuffer, _P, C.POINTER(SvgfParams), _P, C.c_float, _P]),
     "rmd_svgf_context_set_debug_plane": (C.c_int, [_P, _P]),
-    "rmd_svgf_context_history": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "rmd_svgf_context_history": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "rmd_svgf_context_describe": (C.c_int, [_P, C.POINTER(SvgfFrameDesc)]),
     "rmd_strip_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rmd_strip_plan_make": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(SvgfParams), C.POINTER(StripPlan)]),
@@ -130,9 +130,9 @@ SYMBOLS = {
     "rmd_comm_create": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(_P)]),
     "rmd_comm_create_all": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_P)]),
     "rmd_comm_destroy": (C.c_int, [_P]),
-    "rmd_halo_exchange": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, _P, _P, _P]),
-    "rmd_halo_exchange_all": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
-    "rmd_halo_exchange_steps": (C.c_int, [_P, C.c_int, C.POINTER(HaloStep), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "rmd_halo_exchange": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, _P, _P, _P, _P]),
+    "rmd_halo_exchange_all": (C.c_int, [_P, C.POINTER(StripPlan), C.c_int, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "rmd_halo_exchange_steps": (C.c_int, [_P, C.c_int, C.POINTER(HaloStep), C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P]),
     "rmd_exchange_steps": (C.c_int, [_P, C.c_int, C.POINTER(HaloStep), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_P), _P]),
     "rmd_convert_u8_to_f32": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_float, _P]),
     "rmd_convert_f32_to_u8": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),

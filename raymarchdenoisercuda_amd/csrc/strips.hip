@@ -22,7 +22,7 @@ namespace rmd {
 // ---- the handful of RCCL entry points used, with their documented C signatures (rccl.h) ----------
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
-enum { kNcclSuccess = 0, kNcclFloat32 = 7 };
+enum { kNcclSuccess = 0, kNcclUint8 = 1, kNcclFloat32 = 7 };     // rccl.h ncclResult_t / ncclDataType_t
 struct Rccl {
     void* handle = nullptr;
     int (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -167,23 +167,32 @@ int rmd_halo_plan(const rmd_strip_plan* plan, rmd_halo_step* steps, int max_step
     auto clamp = [&](int v) { return v < 0 ? 0 : (v > plan->height ? plan->height : v); };
     if (plan->world > 1) {
         const int up = plan->rank - 1, down = plan->rank + 1, R = plan->reach_hist;
-        const int have[2] = { plan->have_color, plan->have_moments };
-        for (int pl = 0; pl < 2; ++pl) {
-            if (have[pl] >= R) continue;
+        // hist_color; hist_moments; hist_len (T writes the moments and the history length on the same rows)
+        const int planes[3] = { RMD_PLANE_HIST_COLOR, RMD_PLANE_HIST_MOMENTS, RMD_PLANE_HIST_LEN };
+        const int have[3] = { plan->have_color, plan->have_moments, plan->have_moments };
+        for (int q = 0; q < 3; ++q) {
+            const int pl = planes[q];
+            if (have[q] >= R) continue;
             if (up >= 0) {
-                push(RMD_HALO_RECV, pl, clamp(plan->row0 - R), clamp(plan->row0 - have[pl]), up);
+                push(RMD_HALO_RECV, pl, clamp(plan->row0 - R), clamp(plan->row0 - have[q]), up);
                 // rank-1's lower need [row0+have, row0+R) lies in this rank's strip
-                push(RMD_HALO_SEND, pl, clamp(plan->row0 + have[pl]), clamp(plan->row0 + R), up);
+                push(RMD_HALO_SEND, pl, clamp(plan->row0 + have[q]), clamp(plan->row0 + R), up);
             }
             if (down < plan->world) {
-                push(RMD_HALO_RECV, pl, clamp(plan->row1 + have[pl]), clamp(plan->row1 + R), down);
-                push(RMD_HALO_SEND, pl, clamp(plan->row1 - R), clamp(plan->row1 - have[pl]), down);
+                push(RMD_HALO_RECV, pl, clamp(plan->row1 + have[q]), clamp(plan->row1 + R), down);
+                push(RMD_HALO_SEND, pl, clamp(plan->row1 - R), clamp(plan->row1 - have[q]), down);
             }
         }
     }
     *n_steps = n;
     if (steps && n > max_steps) return fail(RMD_E_BUFFER, "rmd_halo_plan: %d steps, room for %d", n, max_steps);
     return RMD_OK;
+}
+
+// bytes per pixel of the planes a halo step may name (include/rmd_api.h RMD_PLANE_*)
+static size_t plane_pixel_bytes(int plane)
+{
+    return plane == RMD_PLANE_HIST_MOMENTS ? 8u : plane == RMD_PLANE_HIST_LEN ? 1u : 16u;
 }
 
 size_t rmd_halo_bytes(const rmd_strip_plan* plan, int width)
@@ -194,7 +203,7 @@ size_t rmd_halo_bytes(const rmd_strip_plan* plan, int width)
     if (rmd_halo_plan(plan, st, RMD_HALO_MAX_STEPS, &n) != RMD_OK) return 0;
     size_t total = 0;
     for (int i = 0; i < n; ++i)
-        if (st[i].kind == RMD_HALO_RECV) total += (size_t)(st[i].row_hi - st[i].row_lo) * (size_t)width * 16u;
+        if (st[i].kind == RMD_HALO_RECV) total += (size_t)(st[i].row_hi - st[i].row_lo) * (size_t)width * plane_pixel_bytes(st[i].plane);
     return total;
 }
 
@@ -257,25 +266,29 @@ int rmd_comm_destroy(rmd_comm* c)
 
 // One rank's part of an exchange: its steps, on its planes, inside an open group.
 static int post_steps(Rccl* r, ncclComm_t comm, const rmd_halo_step* steps, int n, int buf_row0, int buf_rows, int width,
-                      float* hist_color, float* hist_moments, hipStream_t stream, float* mid_plane = nullptr)
+                      void* const planes[RMD_PLANE_COUNT], hipStream_t stream)
 {
     for (int i = 0; i < n; ++i) {
         const rmd_halo_step& s = steps[i];
-        if (s.plane < RMD_PLANE_HIST_COLOR || s.plane > RMD_PLANE_MID) return fail(RMD_E_PARAM, "rmd_halo_exchange: plane index %d", s.plane);
-        float* plane = s.plane == RMD_PLANE_MID ? mid_plane : (s.plane == RMD_PLANE_HIST_COLOR ? hist_color : hist_moments);
+        if (s.plane < 0 || s.plane >= RMD_PLANE_COUNT) return fail(RMD_E_PARAM, "rmd_halo_exchange: plane index %d", s.plane);
+        unsigned char* plane = static_cast<unsigned char*>(planes[s.plane]);
         if (!plane) return fail(RMD_E_NULL, "rmd_halo_exchange: plane %d is NULL", s.plane);
         if (s.row_lo < buf_row0 || s.row_hi > buf_row0 + buf_rows || s.row_lo >= s.row_hi)
             return fail(RMD_E_ROWS, "rmd_halo_exchange: rows [%d,%d) outside the planes [%d,%d)", s.row_lo, s.row_hi, buf_row0, buf_row0 + buf_rows);
-        float* p = plane + (size_t)(s.row_lo - buf_row0) * (size_t)width * 4u;
-        const size_t count = (size_t)(s.row_hi - s.row_lo) * (size_t)width * 4u;
-        if (s.kind == RMD_HALO_SEND) RMD_NCCL(r, r->Send(p, count, kNcclFloat32, s.peer, comm, stream));
-        else                         RMD_NCCL(r, r->Recv(p, count, kNcclFloat32, s.peer, comm, stream));
+        const size_t px = plane_pixel_bytes(s.plane);
+        unsigned char* p = plane + (size_t)(s.row_lo - buf_row0) * (size_t)width * px;
+        const size_t bytes = (size_t)(s.row_hi - s.row_lo) * (size_t)width * px;
+        // float planes travel as floats, the history length plane as bytes
+        const int type = px == 1 ? kNcclUint8 : kNcclFloat32;
+        const size_t count = px == 1 ? bytes : bytes / 4;
+        if (s.kind == RMD_HALO_SEND) RMD_NCCL(r, r->Send(p, count, type, s.peer, comm, stream));
+        else                         RMD_NCCL(r, r->Recv(p, count, type, s.peer, comm, stream));
     }
     return RMD_OK;
 }
 
 int rmd_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
-                       int width, float* const planes[3], void* stream)
+                       int width, void* const planes[RMD_PLANE_COUNT], void* stream)
 {
     if (!c) return fail(RMD_E_NULL, "rmd_halo_exchange: communicator is NULL");
     if (comm_index < 0 || comm_index >= (int)c->comms.size()) return fail(RMD_E_PARAM, "rmd_halo_exchange: communicator index %d", comm_index);
@@ -284,8 +297,7 @@ int rmd_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, 
     Rccl* r = rccl();
     if (!r) return fail(RMD_E_COMM, "rmd_halo_exchange: librccl.so not found");
     RMD_NCCL(r, r->GroupStart());
-    const int e = post_steps(r, c->comms[comm_index], steps, n_steps, buf_row0, buf_rows, width, planes[RMD_PLANE_HIST_COLOR],
-                             planes[RMD_PLANE_HIST_MOMENTS], as_stream(stream), planes[RMD_PLANE_MID]);
+    const int e = post_steps(r, c->comms[comm_index], steps, n_steps, buf_row0, buf_rows, width, planes, as_stream(stream));
     const int g = r->GroupEnd();
     if (e) return e;
     if (g != kNcclSuccess) return nccl_fail(r, g, "ncclGroupEnd");
@@ -293,13 +305,14 @@ int rmd_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, 
 }
 
 int rmd_halo_exchange_steps(rmd_comm* c, int comm_index, const rmd_halo_step* steps, int n_steps, int buf_row0, int buf_rows,
-                            int width, float* hist_color, float* hist_moments, void* stream)
+                            int width, float* hist_color, float* hist_moments, unsigned char* hist_len, void* stream)
 {
-    float* const planes[3] = { hist_color, hist_moments, nullptr };
+    void* const planes[RMD_PLANE_COUNT] = { hist_color, hist_moments, nullptr, hist_len };
     return rmd_exchange_steps(c, comm_index, steps, n_steps, buf_row0, buf_rows, width, planes, stream);
 }
 
-int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* hist_color, float* hist_moments, void* stream)
+int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* hist_color, float* hist_moments,
+                      unsigned char* hist_len, void* stream)
 {
     if (!plan) return fail(RMD_E_NULL, "rmd_halo_exchange: plan is NULL");
     if (c && (int)c->comms.size() != 1) return fail(RMD_E_PARAM, "rmd_halo_exchange: one communicator per process expected; use rmd_halo_exchange_all");
@@ -308,7 +321,7 @@ int rmd_halo_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float*
     if (int e = rmd_halo_plan(plan, st, RMD_HALO_MAX_STEPS, &n)) return e;
     if (n == 0) return RMD_OK;
     if (c && c->world != plan->world) return fail(RMD_E_PARAM, "rmd_halo_exchange: communicator of %d ranks, plan of %d", c->world, plan->world);
-    return rmd_halo_exchange_steps(c, 0, st, n, plan->buf_row0, plan->buf_rows, width, hist_color, hist_moments, stream);
+    return rmd_halo_exchange_steps(c, 0, st, n, plan->buf_row0, plan->buf_rows, width, hist_color, hist_moments, hist_len, stream);
 }
 
 int rmd_mid_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* mid_plane, void* stream)
@@ -325,7 +338,8 @@ int rmd_mid_exchange(rmd_comm* c, const rmd_strip_plan* plan, int width, float* 
     Rccl* r = rccl();
     if (!r) return fail(RMD_E_COMM, "rmd_mid_exchange: librccl.so not found");
     RMD_NCCL(r, r->GroupStart());
-    const int e = post_steps(r, c->comms[0], st, n, plan->buf_row0, plan->buf_rows, width, nullptr, nullptr, as_stream(stream), mid_plane);
+    void* const planes[RMD_PLANE_COUNT] = { nullptr, nullptr, mid_plane, nullptr };
+    const int e = post_steps(r, c->comms[0], st, n, plan->buf_row0, plan->buf_rows, width, planes, as_stream(stream));
     const int g = r->GroupEnd();
     if (e) return e;
     if (g != kNcclSuccess) return nccl_fail(r, g, "ncclGroupEnd");
@@ -348,8 +362,8 @@ int rmd_mid_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, fl
         err = rmd_mid_halo_plan(&plans[k], st, RMD_HALO_MAX_STEPS, &n);
         if (err) break;
         if (hipSetDevice(c->devices[k]) != hipSuccess) { err = fail(RMD_E_PARAM, "rmd_mid_exchange_all: hipSetDevice(%d) failed", c->devices[k]); break; }
-        err = post_steps(r, c->comms[k], st, n, plans[k].buf_row0, plans[k].buf_rows, width, nullptr, nullptr,
-                         as_stream(streams ? streams[k] : nullptr), mid_planes[k]);
+        void* const planes[RMD_PLANE_COUNT] = { nullptr, nullptr, mid_planes[k], nullptr };
+        err = post_steps(r, c->comms[k], st, n, plans[k].buf_row0, plans[k].buf_rows, width, planes, as_stream(streams ? streams[k] : nullptr));
     }
     const int g = r->GroupEnd();
     (void)hipSetDevice(prev);
@@ -359,9 +373,9 @@ int rmd_mid_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, fl
 }
 
 int rmd_halo_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, float* const* hist_color, float* const* hist_moments,
-                          void* const* streams)
+                          unsigned char* const* hist_len, void* const* streams)
 {
-    if (!c || !plans || !hist_color || !hist_moments) return fail(RMD_E_NULL, "rmd_halo_exchange_all: NULL argument");
+    if (!c || !plans || !hist_color || !hist_moments || !hist_len) return fail(RMD_E_NULL, "rmd_halo_exchange_all: NULL argument");
     if ((int)c->comms.size() != c->world) return fail(RMD_E_PARAM, "rmd_halo_exchange_all: needs a communicator from rmd_comm_create_all");
     Rccl* r = rccl();
     if (!r) return fail(RMD_E_COMM, "rmd_halo_exchange_all: librccl.so not found");
@@ -375,8 +389,8 @@ int rmd_halo_exchange_all(rmd_comm* c, const rmd_strip_plan* plans, int width, f
         err = rmd_halo_plan(&plans[k], st, RMD_HALO_MAX_STEPS, &n);
         if (err) break;
         if (hipSetDevice(c->devices[k]) != hipSuccess) { err = fail(RMD_E_PARAM, "rmd_halo_exchange_all: hipSetDevice(%d) failed", c->devices[k]); break; }
-        err = post_steps(r, c->comms[k], st, n, plans[k].buf_row0, plans[k].buf_rows, width, hist_color[k], hist_moments[k],
-                         as_stream(streams ? streams[k] : nullptr));
+        void* const planes[RMD_PLANE_COUNT] = { hist_color[k], hist_moments[k], nullptr, hist_len[k] };
+        err = post_steps(r, c->comms[k], st, n, plans[k].buf_row0, plans[k].buf_rows, width, planes, as_stream(streams ? streams[k] : nullptr));
     }
     const int g = r->GroupEnd();
     (void)hipSetDevice(prev);

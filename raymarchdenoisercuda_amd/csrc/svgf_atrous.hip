@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256, (NP == 1 ? 2 : 3)) void atrous_stream_kernel(A
         g_atrous_trace[6 * pid + 2] = ((unsigned long long)xcc << 32) | hw;
         g_atrous_trace[6 * pid + 3] = ((unsigned long long)L << 8) | (edge ? 1u : 0u);
         g_atrous_trace[6 * pid + 4] = __builtin_amdgcn_s_memtime() - trace_c0;      // shader-clock cycles of this workgroup
-        g_atrous_trace[6 * pid + 5] = (unsigned long long)(jhi - jlo);              // lattice rows it produced
+        g_atrous_trace[6 * pid + 5] = (unsigned long long)(jhi - jlo) | ((unsigned long long)S << 32);   // lattice rows it produced | the launch's step
     }
 #endif
 }

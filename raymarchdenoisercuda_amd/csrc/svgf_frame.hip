@@ -63,9 +63,10 @@ using namespace rmd;
 
 struct rmd_svgf_context {
     int width, height, buf_row0, buf_rows;
-    size_t plane_bytes;
+    size_t plane_bytes;         // of a float4 plane
     float* hist_color[2];
-    float* hist_moments[2];
+    float* hist_moments[2];     // float2 (m1, m2): plane_bytes / 2
+    unsigned char* hist_len[2]; // uint8 history length: plane_bytes / 16
     float* t_color;
     float* v_color;
     float* ping[2];
@@ -340,28 +341,22 @@ int rmd_svgf_context_create(int width, int height, int buf_row0, int buf_rows, r
     c->plane_bytes = (size_t)buf_rows * width * 16;
     c->cur = 0; c->has_history = false;
     c->nd[0] = c->nd[1] = nullptr; c->nd_cur = 0; c->nd_valid = false; c->t_debug = nullptr;
-    float** planes[] = { &c->hist_color[0], &c->hist_color[1], &c->hist_moments[0], &c->hist_moments[1],
-                         &c->t_color, &c->v_color, &c->ping[0], &c->ping[1] };
-    for (float** q : planes) *q = nullptr;
-    for (float** q : planes) {
-        hipError_t e = hipMalloc((void**)q, c->plane_bytes);
-        if (e == hipSuccess) e = hipMemset(*q, 0, c->plane_bytes);
+    c->tile_flags = nullptr;
+    struct { void** p; size_t bytes; } planes[] = {
+        { (void**)&c->hist_color[0], c->plane_bytes }, { (void**)&c->hist_color[1], c->plane_bytes },
+        { (void**)&c->hist_moments[0], c->plane_bytes / 2 }, { (void**)&c->hist_moments[1], c->plane_bytes / 2 },
+        { (void**)&c->hist_len[0], c->plane_bytes / 16 }, { (void**)&c->hist_len[1], c->plane_bytes / 16 },
+        { (void**)&c->t_color, c->plane_bytes }, { (void**)&c->v_color, c->plane_bytes },
+        { (void**)&c->ping[0], c->plane_bytes }, { (void**)&c->ping[1], c->plane_bytes },
+        { (void**)&c->tile_flags, RMD_TILE_FLAGS_BYTES(width, height) } };
+    for (auto& q : planes) *q.p = nullptr;
+    for (auto& q : planes) {
+        hipError_t e = hipMalloc(q.p, q.bytes);
+        if (e == hipSuccess) e = hipMemset(*q.p, 0, q.bytes);
         if (e != hipSuccess) {
-            for (float** z : planes) if (*z) (void)hipFree(*z);
+            for (auto& z : planes) if (*z.p) (void)hipFree(*z.p);
             delete c;
             return hip_fail(e, "rmd_svgf_context_create: hipMalloc");
-        }
-    }
-    c->tile_flags = nullptr;
-    {
-        const size_t fb = RMD_TILE_FLAGS_BYTES(width, height);
-        hipError_t e = hipMalloc((void**)&c->tile_flags, fb);
-        if (e == hipSuccess) e = hipMemset(c->tile_flags, 0, fb);
-        if (e != hipSuccess) {
-            for (float** z : planes) if (*z) (void)hipFree(*z);
-            if (c->tile_flags) (void)hipFree(c->tile_flags);
-            delete c;
-            return hip_fail(e, "rmd_svgf_context_create: hipMalloc(tile flags)");
         }
     }
     *out = c;
@@ -372,9 +367,9 @@ void rmd_svgf_context_destroy(rmd_svgf_context* c)
 {
     if (!c) return;
     if (c->tile_flags) (void)hipFree(c->tile_flags);
-    float* planes[] = { c->hist_color[0], c->hist_color[1], c->hist_moments[0], c->hist_moments[1],
-                        c->t_color, c->v_color, c->ping[0], c->ping[1], c->nd[0], c->nd[1] };
-    for (float* q : planes) if (q) (void)hipFree(q);
+    void* planes[] = { c->hist_color[0], c->hist_color[1], c->hist_moments[0], c->hist_moments[1], c->hist_len[0], c->hist_len[1],
+                       c->t_color, c->v_color, c->ping[0], c->ping[1], c->nd[0], c->nd[1] };
+    for (void* q : planes) if (q) (void)hipFree(q);
     delete c;
 }
 
@@ -385,7 +380,8 @@ int rmd_svgf_context_reset_history(rmd_svgf_context* c, void* stream)
     c->nd_valid = false;
     for (int i = 0; i < 2; ++i) {
         RMD_HIP(hipMemsetAsync(c->hist_color[i], 0, c->plane_bytes, as_stream(stream)));
-        RMD_HIP(hipMemsetAsync(c->hist_moments[i], 0, c->plane_bytes, as_stream(stream)));
+        RMD_HIP(hipMemsetAsync(c->hist_moments[i], 0, c->plane_bytes / 2, as_stream(stream)));
+        RMD_HIP(hipMemsetAsync(c->hist_len[i], 0, c->plane_bytes / 16, as_stream(stream)));
     }
     return RMD_OK;
 }
@@ -396,8 +392,10 @@ int rmd_svgf_context_describe(rmd_svgf_context* c, rmd_svgf_frame_desc* f)
     f->width = c->width; f->height = c->height; f->buf_row0 = c->buf_row0; f->buf_rows = c->buf_rows;
     f->hist_color = c->has_history ? c->hist_color[c->cur] : nullptr;
     f->hist_moments = c->has_history ? c->hist_moments[c->cur] : nullptr;
+    f->hist_len = c->has_history ? c->hist_len[c->cur] : nullptr;
     f->t_color = c->t_color;
     f->t_moments = c->hist_moments[c->cur ^ 1];
+    f->t_len = c->hist_len[c->cur ^ 1];
     f->v_color = c->v_color;
     f->hist_color_out = c->hist_color[c->cur ^ 1];
     f->ping[0] = c->ping[0]; f->ping[1] = c->ping[1];
@@ -417,7 +415,7 @@ static int context_frame_desc(rmd_svgf_context* c, const float* color, const flo
     // the first float-plane frame behind it starts a new history)
     const bool use_hist = c->has_history && prev_nd != nullptr && !c->nd_valid;
     f->prev_nd = use_hist ? prev_nd : nullptr;
-    if (!use_hist) { f->hist_color = nullptr; f->hist_moments = nullptr; }
+    if (!use_hist) { f->hist_color = nullptr; f->hist_moments = nullptr; f->hist_len = nullptr; }
     f->out_color = out;
     f->t_debug = c->t_debug; f->stats = nullptr;
     return RMD_OK;
@@ -504,7 +502,7 @@ int rmd_svgf_gbuffer_frame(rmd_gbuffer frame, rmd_svgf_context* c, const rmd_svg
     rmd_svgf_frame_desc f = {};
     if (int e = rmd_svgf_context_describe(c, &f)) return e;
     const bool use_hist = c->has_history && c->nd_valid;
-    if (!use_hist) { f.hist_color = nullptr; f.hist_moments = nullptr; }
+    if (!use_hist) { f.hist_color = nullptr; f.hist_moments = nullptr; f.hist_len = nullptr; }
     f.color = nullptr; f.motion = motion;
     f.nd = c->nd[c->nd_cur];
     f.prev_nd = use_hist ? c->nd[c->nd_cur ^ 1] : nullptr;
@@ -534,11 +532,12 @@ int rmd_svgf_gbuffer_frame(rmd_gbuffer frame, rmd_svgf_context* c, const rmd_svg
     return RMD_OK;
 }
 
-int rmd_svgf_context_history(rmd_svgf_context* c, float** hist_color, float** hist_moments)
+int rmd_svgf_context_history(rmd_svgf_context* c, float** hist_color, float** hist_moments, unsigned char** hist_len)
 {
-    if (!c || !hist_color || !hist_moments) return fail(RMD_E_NULL, "rmd_svgf_context_history: NULL argument");
+    if (!c || !hist_color || !hist_moments || !hist_len) return fail(RMD_E_NULL, "rmd_svgf_context_history: NULL argument");
     *hist_color = c->hist_color[c->cur];
     *hist_moments = c->hist_moments[c->cur];
+    *hist_len = c->hist_len[c->cur];
     return RMD_OK;
 }
 

@@ -64,11 +64,12 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
     bool spatial = false;
     if (active) {
         const size_t i = pix_index(g, x, y);
-        float4 mom;
+        float2 mom;
         int4 dbg;
         temporal_pixel<IN8>(a, x, y, tc, mom, dbg, nd_own);
         if constexpr (IN8) a.nd_out[i] = nd_own;
         a.t_moments[i] = mom;
+        a.t_len[i] = (unsigned char)dbg.w;
         if (a.t_debug) a.t_debug[i] = dbg;
         h = dbg.w;
         spatial = h < v.h_threshold && y >= v.row0 && y < v.row1;
@@ -100,7 +101,8 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
         // pixels outside the frame are never tapped (A.V skips them); neither are rows outside T's range: V's rows lie
         // at least 3 rows inside it wherever the frame goes on (launch_temporal_variance)
         if (tx < 0 || tx >= g.W || ty < a.row0 || ty >= a.row1) continue;
-        float4 hc, mom, hn;
+        float4 hc, hn;
+        float2 mom;
         int4 dbg;
         temporal_pixel<IN8>(a, tx, ty, hc, mom, dbg, hn);
         scr[ry][rx] = hc.x; scg[ry][rx] = hc.y; scb[ry][rx] = hc.z;
@@ -122,7 +124,8 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
         float4 o = variance_window_lds([&](int ry, int rx) { return make_float4(scr[ry][rx], scg[ry][rx], scb[ry][rx], 0.0f); },
                                        [&](int ry, int rx) { return sn[ry][rx]; }, px, py, x0 + px, y0 + py, g, v.sigma_n, v.sigma_z, id >> 8, keep);
         if (keep) {                                        // weights vanished (normals that break the unit-length contract): the pixel
-            float4 mom, kn;                                // keeps T's value, whose variance only the lane that computed it had
+            float4 kn;                                     // keeps T's value, whose variance only the lane that computed it had
+            float2 mom;
             int4 dbg;
             temporal_pixel<IN8>(a, x0 + px, y0 + py, o, mom, dbg, kn);
         }
@@ -183,30 +186,31 @@ int rmd::make_temporal_args(const rmd_svgf_frame_desc* f, const rmd_svgf_params*
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_temporal: params is NULL");
-    if (!f->color || !f->nd || !f->motion || !f->t_color || !f->t_moments)
+    if (!f->color || !f->nd || !f->motion || !f->t_color || !f->t_moments || !f->t_len)
         return fail(RMD_E_NULL, "rmd_svgf_temporal: a required plane is NULL");
-    // hist_color / hist_moments / prev_nd all NULL = "no history": every pixel is a disocclusion
-    const bool has_hist = f->hist_color && f->hist_moments && f->prev_nd;
-    if (!has_hist && (f->hist_color || f->hist_moments || f->prev_nd))
+    // hist_color / hist_moments / hist_len / prev_nd all NULL = "no history": every pixel is a disocclusion
+    const bool has_hist = f->hist_color && f->hist_moments && f->hist_len && f->prev_nd;
+    if (!has_hist && (f->hist_color || f->hist_moments || f->hist_len || f->prev_nd))
         return fail(RMD_E_NULL, "rmd_svgf_temporal: history planes must be all set or all NULL");
     if (row0 < 0 || row1 > f->height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_svgf_temporal: rows [%d,%d) invalid", row0, row1);
-    if (p->max_motion_rows < 0 || p->h_max < 1) return fail(RMD_E_PARAM, "rmd_svgf_temporal: max_motion_rows/h_max invalid");
+    if (p->max_motion_rows < 0 || p->h_max < 1 || p->h_max > 255) return fail(RMD_E_PARAM, "rmd_svgf_temporal: max_motion_rows < 0 or h_max outside [1,255]");
     if (p->tv_workgroups < 0 || p->tv_workgroups > 65536) return fail(RMD_E_PARAM, "rmd_svgf_temporal: tv_workgroups %d outside [0,65536]", p->tv_workgroups);
     // current-frame planes: +1 row (depth gradient); history planes: +-(max_motion_rows) rows
     if (int e = check_rows_in_buffer(f, row0, row1 + 1, "rmd_svgf_temporal (current frame)")) return e;
     if (has_hist)
         if (int e = check_rows_in_buffer(f, row0 - p->max_motion_rows, row1 + p->max_motion_rows, "rmd_svgf_temporal (history)")) return e;
-    const void* planes16[] = { f->color, f->nd, f->hist_color, f->hist_moments, f->prev_nd, f->t_color, f->t_moments, f->t_debug };
+    const void* planes16[] = { f->color, f->nd, f->hist_color, f->prev_nd, f->t_color, f->t_debug };
     for (const void* q : planes16)
         if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_temporal: float4 planes must be 16-byte aligned");
-    if (!aligned_to(f->motion, 8)) return fail(RMD_E_ALIGN, "rmd_svgf_temporal: motion must be 8-byte aligned");
+    if (!aligned_to(f->motion, 8) || !aligned_to(f->hist_moments, 8) || !aligned_to(f->t_moments, 8))
+        return fail(RMD_E_ALIGN, "rmd_svgf_temporal: float2 planes (motion, moments) must be 8-byte aligned");
 
     TemporalArgs a;
     a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
     a.color = (const float4*)f->color; a.nd = (const float4*)f->nd; a.motion = (const float2*)f->motion;
-    a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float4*)f->hist_moments;
+    a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float2*)f->hist_moments; a.hist_len = f->hist_len;
     a.prev_nd = (const float4*)f->prev_nd;
-    a.t_color = (float4*)f->t_color; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
+    a.t_color = (float4*)f->t_color; a.t_moments = (float2*)f->t_moments; a.t_len = f->t_len; a.t_debug = (int4*)f->t_debug;
     a.v_color = nullptr;
     a.render8 = a.albedo8 = a.normal8 = nullptr; a.nd_out = nullptr; a.albedo_eps = 0.0f;
     a.sparse_t_color = (fused && sparse_t_color) ? 1 : 0;
@@ -264,16 +268,16 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_frame_tv: params is NULL");
     // 8-bit front end: render / albedo / normal are the inputs, f->nd is WRITTEN, f->color is not used, f->motion may be NULL
     if (g8) {
-        if (!g8->render || !g8->albedo || !g8->normal || !f->nd || !f->t_moments || !f->v_color)
+        if (!g8->render || !g8->albedo || !g8->normal || !f->nd || !f->t_moments || !f->t_len || !f->v_color)
             return fail(RMD_E_NULL, "rmd_svgf_gbuffer_frame: a required plane is NULL");
         if (!aligned_to(g8->render, 4) || !aligned_to(g8->albedo, 4) || !aligned_to(g8->normal, 4))
             return fail(RMD_E_ALIGN, "rmd_svgf_gbuffer_frame: uchar4 planes must be 4-byte aligned");
         if (!(g8->albedo_eps > 0.0f)) return fail(RMD_E_PARAM, "rmd_svgf_gbuffer_frame: albedo_eps must be > 0");
         if (f->nd == f->prev_nd) return fail(RMD_E_BUFFER, "rmd_svgf_gbuffer_frame: the nd plane written aliases prev_nd");
-    } else if (!f->color || !f->nd || !f->motion || !f->t_moments || !f->v_color)
+    } else if (!f->color || !f->nd || !f->motion || !f->t_moments || !f->t_len || !f->v_color)
         return fail(RMD_E_NULL, "rmd_svgf_frame_tv: a required plane is NULL");
-    const bool has_hist = f->hist_color && f->hist_moments && f->prev_nd;
-    if (!has_hist && (f->hist_color || f->hist_moments || f->prev_nd))
+    const bool has_hist = f->hist_color && f->hist_moments && f->hist_len && f->prev_nd;
+    if (!has_hist && (f->hist_color || f->hist_moments || f->hist_len || f->prev_nd))
         return fail(RMD_E_NULL, "rmd_svgf_frame_tv: history planes must be all set or all NULL");
     if (row0 < 0 || row1 > f->height || row0 >= row1 || v_row0 < row0 || v_row1 > row1 || v_row0 >= v_row1)
         return fail(RMD_E_ROWS, "rmd_svgf_frame_tv: rows T [%d,%d) V [%d,%d) invalid", row0, row1, v_row0, v_row1);
@@ -281,14 +285,15 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
     if ((v_row0 - kVR < row0 && row0 > 0) || (v_row1 + kVR > row1 && row1 < f->height))
         return fail(RMD_E_ROWS, "rmd_svgf_frame_tv: V rows [%d,%d) need T on %d more rows than [%d,%d)", v_row0, v_row1, kVR, row0, row1);
     if (p->var_radius != kVR) return fail(RMD_E_PARAM, "rmd_svgf_frame_tv: the fused kernel is built for var_radius %d", kVR);
-    if (p->max_motion_rows < 0 || p->h_max < 1) return fail(RMD_E_PARAM, "rmd_svgf_frame_tv: max_motion_rows/h_max invalid");
+    if (p->max_motion_rows < 0 || p->h_max < 1 || p->h_max > 255) return fail(RMD_E_PARAM, "rmd_svgf_frame_tv: max_motion_rows < 0 or h_max outside [1,255]");
     if (int e = check_rows_in_buffer(f, row0, row1 + 1, "rmd_svgf_frame_tv (current frame)")) return e;
     if (has_hist)
         if (int e = check_rows_in_buffer(f, row0 - p->max_motion_rows, row1 + p->max_motion_rows, "rmd_svgf_frame_tv (history)")) return e;
-    const void* planes16[] = { g8 ? nullptr : f->color, f->nd, f->hist_color, f->hist_moments, f->prev_nd, f->v_color, f->t_moments, f->t_debug };
+    const void* planes16[] = { g8 ? nullptr : f->color, f->nd, f->hist_color, f->prev_nd, f->v_color, f->t_debug };
     for (const void* q : planes16)
         if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_frame_tv: float4 planes must be 16-byte aligned");
-    if (!aligned_to(f->motion, 8)) return fail(RMD_E_ALIGN, "rmd_svgf_frame_tv: motion must be 8-byte aligned");
+    if (!aligned_to(f->motion, 8) || !aligned_to(f->hist_moments, 8) || !aligned_to(f->t_moments, 8))
+        return fail(RMD_E_ALIGN, "rmd_svgf_frame_tv: float2 planes (motion, moments) must be 8-byte aligned");
 
     TemporalArgs a;
     a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
@@ -298,9 +303,9 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
         a.color = nullptr; a.nd = nullptr;
         a.render8 = g8->render; a.albedo8 = g8->albedo; a.normal8 = g8->normal; a.nd_out = (float4*)f->nd; a.albedo_eps = g8->albedo_eps;
     }
-    a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float4*)f->hist_moments;
+    a.hist_color = (const float4*)f->hist_color; a.hist_moments = (const float2*)f->hist_moments; a.hist_len = f->hist_len;
     a.prev_nd = (const float4*)f->prev_nd;
-    a.t_color = nullptr; a.t_moments = (float4*)f->t_moments; a.t_debug = (int4*)f->t_debug;
+    a.t_color = nullptr; a.t_moments = (float2*)f->t_moments; a.t_len = f->t_len; a.t_debug = (int4*)f->t_debug;
     a.v_color = (float4*)f->v_color;
     a.sparse_t_color = 0;
     a.tile_flags = f->v_tile_flags; a.tiles_x = (f->width + 63) / 64; a.var_h_threshold = p->var_h_threshold;

@@ -10,8 +10,8 @@ namespace rmd {
 struct TemporalArgs {
     Geom g;
     const float4* color; const float4* nd; const float2* motion;
-    const float4* hist_color; const float4* hist_moments; const float4* prev_nd;
-    float4* t_color; float4* t_moments; int4* t_debug;
+    const float4* hist_color; const float2* hist_moments; const unsigned char* hist_len; const float4* prev_nd;
+    float4* t_color; float2* t_moments; unsigned char* t_len; int4* t_debug;
     float4* v_color;          // optional second copy of t_color (fused frame: V then only rewrites short-history pixels)
     unsigned char* tile_flags; // optional: 1 per 64x4 tile (global tiling) holding a pixel with h < var_h_threshold
     int tiles_x, var_h_threshold;
@@ -50,12 +50,15 @@ unsigned* side_counter_on_device();        // one zero-initialised word per devi
 
 __device__ __forceinline__ float lerpf(float a, float b, float t) { return a + (b - a) * t; }
 
-// Appendix A.T for ONE pixel (x, y) inside the frame and the buffer: returns c' + variance in `tc`, the moments in `mom`,
-// the bit-exact integer outputs in `dbg`, the pixel's (normal, depth) in `nd`.  Stores nothing.
+// Appendix A.T for ONE pixel (x, y) inside the frame and the buffer: returns c' + variance in `tc`, the moments (m1', m2') in
+// `mom` (the history length h is dbg.w), the bit-exact integer outputs in `dbg`, the pixel's (normal, depth) in `nd`.  Stores nothing.
+// The history planes are read as they are stored: hist_color float4 (its variance channel is not used: T recomputes the variance
+// from the moments), hist_moments float2, hist_len one byte -- 16 + 8 + 1 bytes per tap instead of the 16 + 16 of a float4
+// (m1, m2, h, 0) plane.
 // IN8: illumination and (normal, depth) come from the GBuffer's uchar4 planes -- rmd_convert_u8_to_f32 (render, albedo: c/255;
 // normal: c/255 renormalised, w/255 = depth) and rmd_demodulate in registers, the operations of those kernels in their order.
 template <bool IN8 = false>
-__device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int x, const int y, float4& tc, float4& mom, int4& dbg, float4& nd)
+__device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int x, const int y, float4& tc, float2& mom, int4& dbg, float4& nd)
 {
     const Geom g = a.g;
     const size_t i = pix_index(g, x, y);
@@ -103,7 +106,9 @@ __device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int 
         const int yhi = min(min(g.buf_row0 + g.buf_rows, g.H) - 1, y + a.max_motion_rows);
         size_t ti[4];
         bool inb[4];
-        float4 pn[4], hc[4], hm[4];
+        float4 pn[4], hc[4];
+        float2 hm[4];
+        unsigned char hl[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int tx = q0x + (k & 1), ty = q0y + (k >> 1);
@@ -122,7 +127,7 @@ __device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int 
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { hc[k] = a.hist_color[ti[k]]; hm[k] = a.hist_moments[ti[k]]; }
+        for (int k = 0; k < 4; ++k) { hc[k] = a.hist_color[ti[k]]; hm[k] = a.hist_moments[ti[k]]; hl[k] = a.hist_len[ti[k]]; }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!ok[k]) continue;
@@ -131,7 +136,7 @@ __device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int 
             wsum += w;
             pcx += w * hc[k].x; pcy += w * hc[k].y; pcz += w * hc[k].z;
             pm1 += w * hm[k].x; pm2 += w * hm[k].y;
-            if (w > best_w) { best_w = w; best_h = (int)hm[k].z; }
+            if (w > best_w) { best_w = w; best_h = (int)hl[k]; }
         }
     }
 
@@ -156,7 +161,7 @@ __device__ __forceinline__ void temporal_pixel(const TemporalArgs& a, const int 
     if (!(var > 0.0f)) var = 0.0f;
 
     tc = make_float4(lerpf(pcx, c.x, a_c), lerpf(pcy, c.y, a_c), lerpf(pcz, c.z, a_c), var);
-    mom = make_float4(m1, m2, (float)h, 0.0f);
+    mom = make_float2(m1, m2);
     dbg = make_int4(q0x, q0y, mask, h);
 }
 
@@ -172,12 +177,14 @@ __device__ __forceinline__ void temporal_tile(const TemporalArgs& a, const int t
     size_t i = 0;
     if (active) {
         i = pix_index(g, x, y);
-        float4 mom, nd;
+        float4 nd;
+        float2 mom;
         int4 dbg;
         temporal_pixel(a, x, y, tc, mom, dbg, nd);
         if (!a.sparse_t_color) a.t_color[i] = tc;
         if (a.v_color) a.v_color[i] = tc;
         a.t_moments[i] = mom;
+        a.t_len[i] = (unsigned char)dbg.w;
         if (a.t_debug) a.t_debug[i] = dbg;
         short_history = dbg.w < a.var_h_threshold;
     }

@@ -17,7 +17,7 @@ namespace rmd {
 
 struct VarianceArgs {
     Geom g;
-    const float4* t_color; const float4* t_moments; const float4* nd;
+    const float4* t_color; const unsigned char* t_len; const float4* nd;
     float4* v_color; float* stats;
     int row0, row1;
     int h_threshold, radius;
@@ -46,7 +46,7 @@ __device__ __forceinline__ void variance_pixel(const VarianceArgs& a, const int 
     s[0] = s[1] = s[2] = s[3] = 0.0f;
     if (active) {
         const size_t i = pix_index(g, x, y);
-        const int h = (int)a.t_moments[i].z;
+        const int h = (int)a.t_len[i];
         const bool spatial = h < a.h_threshold;
         if (!spatial && a.prefilled) return;       // (prefilled launches collect no statistics; s stays 0)
         const float4 c = a.t_color[i];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void svgf_variance_tile_kernel(VarianceArgs a,
             {
                 const int x = x0 + (threadIdx.x & 63), y = y0 + (threadIdx.x >> 6);
                 const bool active = x < g.W && y >= a.row0 && y < a.row1;
-                if (active) h = (int)a.t_moments[pix_index(g, x, y)].z;
+                if (active) h = (int)a.t_len[pix_index(g, x, y)];
                 const bool spatial = active && h < a.h_threshold;  // (else v_color already holds t_color)
                 const unsigned long long b = __builtin_amdgcn_ballot_w64(spatial);
                 const int wave = threadIdx.x >> 6;
@@ -266,12 +266,12 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
 {
     if (int e = check_frame_geometry(f)) return e;
     if (!p) return fail(RMD_E_NULL, "rmd_svgf_variance: params is NULL");
-    if (!f->t_color || !f->t_moments || !f->nd || !f->v_color) return fail(RMD_E_NULL, "rmd_svgf_variance: a required plane is NULL");
+    if (!f->t_color || !f->t_len || !f->nd || !f->v_color) return fail(RMD_E_NULL, "rmd_svgf_variance: a required plane is NULL");
     if (row0 < 0 || row1 > f->height || row0 >= row1) return fail(RMD_E_ROWS, "rmd_svgf_variance: rows [%d,%d) invalid", row0, row1);
     if (p->var_radius < 0 || p->var_radius > 16) return fail(RMD_E_PARAM, "rmd_svgf_variance: var_radius %d outside [0,16]", p->var_radius);
     const int reach = p->var_radius > 1 ? p->var_radius : 1;
     if (int e = check_rows_in_buffer(f, row0 - reach, row1 + reach, "rmd_svgf_variance")) return e;
-    const void* planes16[] = { f->t_color, f->t_moments, f->nd, f->v_color };
+    const void* planes16[] = { f->t_color, f->nd, f->v_color };
     for (const void* q : planes16)
         if (!aligned_to(q, 16)) return fail(RMD_E_ALIGN, "rmd_svgf_variance: float4 planes must be 16-byte aligned");
     if (f->t_color == f->v_color) return fail(RMD_E_BUFFER, "rmd_svgf_variance: t_color and v_color alias");
@@ -279,7 +279,7 @@ int rmd::launch_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_params* p,
 
     VarianceArgs a;
     a.g = Geom{ f->width, f->height, f->buf_row0, f->buf_rows };
-    a.t_color = (const float4*)f->t_color; a.t_moments = (const float4*)f->t_moments; a.nd = (const float4*)f->nd;
+    a.t_color = (const float4*)f->t_color; a.t_len = f->t_len; a.nd = (const float4*)f->nd;
     a.v_color = (float4*)f->v_color; a.stats = f->stats;
     a.row0 = row0; a.row1 = row1;
     a.h_threshold = p->var_h_threshold; a.radius = p->var_radius;

@@ -335,7 +335,7 @@ TEST(SVGF_STRIPS)
                 rmd_synth_desc d = { W, H, pl.buf_row0, pl.buf_rows, 1234u, f, 1.25f, -0.5f };
                 rmdCheck(rmd_synth_gbuffer(&d, color[k][f].data(), nd[k][f].data(), motion[k][f].data(), nullptr, nullptr), "synth strip");
             }
-            expect(pl.haloSteps().size() == (k == 0 || k == world - 1 ? 4u : 8u), "a border rank exchanges with one neighbour, an inner rank with two");
+            expect(pl.haloSteps().size() == (k == 0 || k == world - 1 ? 6u : 12u), "three history planes x (send + receive): a border rank exchanges with one neighbour, an inner rank with two");
             expect(pl.midSteps().size() == (exchange < 0 ? 0u : (k == 0 || k == world - 1 ? 2u : 4u)), "the mid-frame exchange: one send and one receive per neighbour");
         }
         rmdCheck(rmd_device_sync(), "sync");

@@ -5,7 +5,7 @@ torch.distributed with backend "nccl" (= RCCL over xGMI).  A frame of H rows is 
 contiguous full-width row strips; each rank runs the whole SVGF pipeline on its strip plus the
 rows later passes tap (redundant rows, no per-pass exchange), so within a frame there is no
 communication at all.  The only cross-rank data is the temporal feedback: next frame's history
-halo.  A rank already holds hist_color on +-reach[2] rows and hist_moments on +-reach[3] rows of
+halo.  A rank already holds hist_color on +-reach[2] rows and hist_moments / hist_len on +-reach[3] rows of
 its strip, bit-identical to its neighbours' copies, so only the rows beyond that, up to
 reach[1], travel: point-to-point isend/irecv with rank+-1, one batched group per frame (one
 direct xGMI link per neighbour; no all-reduce anywhere).
@@ -31,7 +31,7 @@ class StripPlan:
     reach_in: int      # current-frame input rows read beyond the strip
     reach_hist: int    # history rows read beyond the strip
     have_color: int    # hist_color rows this rank produces itself beyond the strip
-    have_moments: int  # hist_moments rows this rank produces itself beyond the strip
+    have_moments: int  # hist_moments / hist_len rows this rank produces itself beyond the strip
     mid_iteration: int = -1   # a-trous iteration whose output crosses ranks INSIDE a frame (rmd_svgf_params.exchange_iteration)
     mid_rows: int = 0         # rows per side that travel in that exchange
 
@@ -69,7 +69,8 @@ def _rows(plane, plan, lo, hi):
 
 def halo_plan(plan: StripPlan):
     """The per-frame exchange of one rank as plain data: a list of
-    (kind, plane, lo, hi, peer) with kind in {"recv", "send"}, plane in {"color", "moments"} and
+    (kind, plane, lo, hi, peer) with kind in {"recv", "send"}, plane in {"color", "moments", "len"} (hist_color float4,
+    hist_moments float2, hist_len uint8: T writes the last two on the same rows) and
     [lo,hi) GLOBAL rows.  From rank-1 a rank needs rows [row0-reach_hist, row0-have); from rank+1
     rows [row1+have, row1+reach_hist); the sends mirror the neighbours' needs.  Rows outside the
     frame do not exist and are skipped.  recv/send pairs of two neighbours appear in matching
@@ -80,7 +81,7 @@ def halo_plan(plan: StripPlan):
         return steps
     up, down = plan.rank - 1, plan.rank + 1
     H = plan.height
-    for name, have in (("color", plan.have_color), ("moments", plan.have_moments)):
+    for name, have in (("color", plan.have_color), ("moments", plan.have_moments), ("len", plan.have_moments)):
         if have >= plan.reach_hist:
             continue
         if up >= 0:
@@ -118,9 +119,9 @@ def mid_halo_plan(plan: StripPlan):
     return [s for s in steps if s[3] > s[2]]
 
 
-def halo_ops(plan: StripPlan, hist_color, hist_moments, group=None):
+def halo_ops(plan: StripPlan, hist_color, hist_moments, hist_len, group=None):
     """torch.distributed P2P ops for halo_plan(plan) on this rank's history planes."""
-    planes = {"color": hist_color, "moments": hist_moments}
+    planes = {"color": hist_color, "moments": hist_moments, "len": hist_len}
     ops = []
     for kind, name, lo, hi, peer in halo_plan(plan):
         fn = dist.irecv if kind == "recv" else dist.isend
@@ -128,13 +129,13 @@ def halo_ops(plan: StripPlan, hist_color, hist_moments, group=None):
     return ops
 
 
-def exchange_history_halo(plan: StripPlan, hist_color, hist_moments, group=None):
+def exchange_history_halo(plan: StripPlan, hist_color, hist_moments, hist_len, group=None):
     """Blocking form: post the batched isend/irecv group and wait for it.
 
     With RCCL ("nccl") the device rows travel directly over xGMI.  With gloo and device planes (the
     one-GPU rehearsal of the multi-rank path) the rows are staged through host memory.
     """
-    return _exchange(plan, halo_plan(plan), {"color": hist_color, "moments": hist_moments}, group)
+    return _exchange(plan, halo_plan(plan), {"color": hist_color, "moments": hist_moments, "len": hist_len}, group)
 
 
 def exchange_mid_halo(plan: StripPlan, mid_plane, group=None):
@@ -169,6 +170,9 @@ def _exchange(plan, steps, planes, group):
     return len(steps)
 
 
+PLANE_PIXEL_BYTES = {"color": 16, "moments": 8, "len": 1, "mid": 16}
+
+
 def mid_halo_bytes(plan: StripPlan, width):
     """Bytes this rank receives in the mid-frame exchange."""
     return sum((hi - lo) * width * 16 for kind, _, lo, hi, _ in mid_halo_plan(plan) if kind == "recv")
@@ -176,14 +180,7 @@ def mid_halo_bytes(plan: StripPlan, width):
 
 def halo_bytes(plan: StripPlan, width):
     """History bytes this rank receives per frame (for reporting)."""
-    total = 0
-    for have in (plan.have_color, plan.have_moments):
-        rows = max(0, plan.reach_hist - have)
-        if plan.rank > 0:
-            total += min(rows, plan.row0) * width * 16
-        if plan.rank < plan.world - 1:
-            total += min(rows, plan.height - plan.row1) * width * 16
-    return total
+    return sum((hi - lo) * width * PLANE_PIXEL_BYTES[name] for kind, name, lo, hi, _ in halo_plan(plan) if kind == "recv")
 
 
 class _NoExchange:
@@ -242,8 +239,7 @@ class ShardedDenoiser:
     # ---- pipelined form: the history halo lazily, on the stream T runs on
     def _complete_halo(self):
         if self._halo_pending:
-            hc, hm = self.den.history()
-            exchange_history_halo(self.plan, hc, hm, self.group)
+            exchange_history_halo(self.plan, *self.den.history(), self.group)
             self._halo_pending = False
 
     # ---- serial form: hooks of SvgfDenoiser.denoise
@@ -263,11 +259,11 @@ class ShardedDenoiser:
         """Next frame's history planes are complete behind `event`: exchange their halo rows now, beside the remaining
         a-trous iterations."""
         den = self.den
-        hc, hm = den.hist_color[den.cur ^ 1], den.hist_moments[den.cur ^ 1]      # what the NEXT frame reads
+        hc, hm, hl = den.hist_color[den.cur ^ 1], den.hist_moments[den.cur ^ 1], den.hist_len[den.cur ^ 1]      # what the NEXT frame reads
         if self.comm_stream is None:
-            exchange_history_halo(self.plan, hc, hm, self.group)
+            exchange_history_halo(self.plan, hc, hm, hl, self.group)
         else:
-            self._on_comm_stream(event, lambda: exchange_history_halo(self.plan, hc, hm, self.group), self._hist_done)
+            self._on_comm_stream(event, lambda: exchange_history_halo(self.plan, hc, hm, hl, self.group), self._hist_done)
         self._halo_pending = True
 
     def mid_ready(self, plane):

@@ -12,8 +12,9 @@ import torch
 from ._lib import SvgfFrameDesc, SvgfParams, SynthDesc, check, lib
 from .filter import _stream_ptr
 
-PLANE_CHANNELS = {"color": 4, "nd": 4, "motion": 2, "hist_color": 4, "hist_moments": 4, "prev_nd": 4,
-                  "t_color": 4, "t_moments": 4, "t_debug": 4, "v_color": 4, "hist_color_out": 4,
+# channels per pixel (0: a plane of shape [rows, width], one byte per pixel)
+PLANE_CHANNELS = {"color": 4, "nd": 4, "motion": 2, "hist_color": 4, "hist_moments": 2, "hist_len": 0, "prev_nd": 4,
+                  "t_color": 4, "t_moments": 2, "t_len": 0, "t_debug": 4, "v_color": 4, "hist_color_out": 4,
                   "out_color": 4}
 
 
@@ -53,8 +54,9 @@ def _ptr(t, name, rows, width, channels, dtype=torch.float32):
         return None
     if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
         raise ValueError(f"{name}: expected a contiguous CUDA {dtype} tensor")
-    if tuple(t.shape) != (rows, width, channels):
-        raise ValueError(f"{name}: shape {tuple(t.shape)} != {(rows, width, channels)}")
+    want = (rows, width, channels) if channels else (rows, width)
+    if tuple(t.shape) != want:
+        raise ValueError(f"{name}: shape {tuple(t.shape)} != {want}")
     return t.data_ptr()
 
 
@@ -72,7 +74,7 @@ def frame_desc(width, height, buf_row0=0, buf_rows=None, ping=(None, None), stat
     for name, t in planes.items():
         if name not in PLANE_CHANNELS:
             raise KeyError(name)
-        dtype = torch.int32 if name == "t_debug" else torch.float32
+        dtype = torch.int32 if name == "t_debug" else torch.uint8 if PLANE_CHANNELS[name] == 0 else torch.float32
         setattr(d, name, _ptr(t, name, buf_rows, width, PLANE_CHANNELS[name], dtype))
     d.ping[0] = _ptr(ping[0], "ping[0]", buf_rows, width, 4)
     d.ping[1] = _ptr(ping[1], "ping[1]", buf_rows, width, 4)
@@ -170,7 +172,10 @@ class SvgfDenoiser:
             return torch.zeros((self.buf_rows, width, 4), dtype=torch.float32, device=device)
 
         self.hist_color = [plane(), plane()]
-        self.hist_moments = [plane(), plane()]
+        # the luminance moments (m1, m2) as float2 and the history length as one byte per pixel: 9 of the 16 bytes a float4
+        # (m1, m2, h, 0) would move per tap and per pixel written (include/rmd_api.h rmd_svgf_frame_desc)
+        self.hist_moments = [torch.zeros((self.buf_rows, width, 2), dtype=torch.float32, device=device) for _ in range(2)]
+        self.hist_len = [torch.zeros((self.buf_rows, width), dtype=torch.uint8, device=device) for _ in range(2)]
         self.t_color, self.v_color = plane(), plane()
         self.ping = [plane(), plane()]
         self.t_debug = torch.zeros((self.buf_rows, width, 4), dtype=torch.int32, device=device) if debug else None
@@ -204,8 +209,8 @@ class SvgfDenoiser:
         self.prev_nd = None
 
     def history(self):
-        """(hist_color, hist_moments) the NEXT denoise call reads."""
-        return self.hist_color[self.cur], self.hist_moments[self.cur]
+        """(hist_color, hist_moments, hist_len) the NEXT denoise call reads."""
+        return self.hist_color[self.cur], self.hist_moments[self.cur], self.hist_len[self.cur]
 
     def synchronize(self):
         if self.pipelined:
@@ -225,8 +230,9 @@ class SvgfDenoiser:
             color=color, nd=nd, motion=motion,
             hist_color=self.hist_color[cur] if use_hist else None,
             hist_moments=self.hist_moments[cur] if use_hist else None,
+            hist_len=self.hist_len[cur] if use_hist else None,
             prev_nd=prev_nd if use_hist else None,
-            t_color=self.t_color, t_moments=self.hist_moments[cur ^ 1], t_debug=self.t_debug,
+            t_color=self.t_color, t_moments=self.hist_moments[cur ^ 1], t_len=self.hist_len[cur ^ 1], t_debug=self.t_debug,
             v_color=self.v_color, hist_color_out=self.hist_color[cur ^ 1],
             ping=(self.ping[0], self.ping[1]), out_color=out, stats=self.stats, tile_flags=self.tile_flags)
 
@@ -368,14 +374,15 @@ class GBufferDenoiser:
         return denoised
 
     def history(self):
-        """Copies of (hist_color, hist_moments) the NEXT frame reads, as float32 [H, W, 4] CUDA tensors."""
-        hc, hm = C.c_void_p(), C.c_void_p()
-        check(lib.rmd_svgf_context_history(self._ctx, C.byref(hc), C.byref(hm)))
+        """Copies of (hist_color, hist_moments, hist_len) the NEXT frame reads: float32 [H, W, 4], float32 [H, W, 2], uint8 [H, W]."""
+        hc, hm, hl = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.rmd_svgf_context_history(self._ctx, C.byref(hc), C.byref(hm), C.byref(hl)))
         out = []
-        for ptr in (hc, hm):
-            t = torch.empty((self.height, self.width, 4), dtype=torch.float32, device="cuda")
-            torch.cuda.current_stream().synchronize()
-            check(lib.rmd_memcpy_d2d(t.data_ptr(), ptr, t.numel() * 4, None))
-            check(lib.rmd_device_sync())
+        torch.cuda.current_stream().synchronize()
+        for ptr, shape, dtype in ((hc, (self.height, self.width, 4), torch.float32), (hm, (self.height, self.width, 2), torch.float32),
+                                  (hl, (self.height, self.width), torch.uint8)):
+            t = torch.empty(shape, dtype=dtype, device="cuda")
+            check(lib.rmd_memcpy_d2d(t.data_ptr(), ptr, t.numel() * t.element_size(), None))
             out.append(t)
+        check(lib.rmd_device_sync())
         return tuple(out)

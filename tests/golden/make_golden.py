@@ -29,11 +29,12 @@ def run_sequence(width, height, inputs, params):
         orc.frame(fr, params)
         out[f"f{i}_t_color"] = fr.t_color.copy()
         out[f"f{i}_t_moments"] = fr.t_moments.copy()
+        out[f"f{i}_t_len"] = fr.t_len.copy()
         out[f"f{i}_t_debug"] = fr.t_debug.copy()
         out[f"f{i}_v_color"] = fr.v_color.copy()
         out[f"f{i}_hist_color_out"] = fr.hist_color_out.copy()
         out[f"f{i}_out_color"] = fr.out_color.copy()
-        hist_c, hist_m, prev_nd = fr.hist_color_out, fr.t_moments, fr.nd
+        hist_c, hist_m, prev_nd = fr.history()
     return out
 
 

@@ -166,7 +166,11 @@ def weighted_filter(render_rgba: np.ndarray, params, normal=None, albedo=None) -
 class Frame:
     """Host planes of one SVGF frame (numpy float32) + the descriptor the oracle reads."""
 
-    def __init__(self, width, height, color, nd, motion, hist_color=None, hist_moments=None, prev_nd=None, debug=True):
+    def __init__(self, width, height, color, nd, motion, hist_color=None, hist_moments=None, prev_nd=None, debug=True, hist_len=None):
+        """History of the previous frame: (hist_color, hist_moments, prev_nd) + hist_len -- or hist_moments given as the
+        PAIR (t_moments, t_len) of the previous Frame (see `history()`)."""
+        if isinstance(hist_moments, tuple):
+            hist_moments, hist_len = hist_moments
         self.width, self.height = width, height
         f4 = lambda: np.zeros((height, width, 4), np.float32)  # noqa: E731
         self.color = np.ascontiguousarray(color, np.float32)
@@ -174,19 +178,28 @@ class Frame:
         self.motion = np.ascontiguousarray(motion, np.float32)
         self.hist_color = None if hist_color is None else np.ascontiguousarray(hist_color, np.float32)
         self.hist_moments = None if hist_moments is None else np.ascontiguousarray(hist_moments, np.float32)
+        self.hist_len = None if hist_len is None else np.ascontiguousarray(hist_len, np.uint8)
+        assert (self.hist_moments is None) == (self.hist_len is None), "hist_moments and hist_len come together"
+        assert self.hist_moments is None or (self.hist_moments.shape == (height, width, 2) and self.hist_len.shape == (height, width))
         self.prev_nd = None if prev_nd is None else np.ascontiguousarray(prev_nd, np.float32)
-        self.t_color, self.t_moments, self.v_color = f4(), f4(), f4()
+        self.t_color, self.v_color = f4(), f4()
+        self.t_moments = np.zeros((height, width, 2), np.float32)        # float2 (m1, m2)
+        self.t_len = np.zeros((height, width), np.uint8)                 # history length
         self.t_debug = np.zeros((height, width, 4), np.int32) if debug else None
         self.hist_color_out, self.out_color = f4(), f4()
         self.ping = [f4(), f4()]
         self.desc = SvgfFrameDesc()
         d = self.desc
         d.width, d.height, d.buf_row0, d.buf_rows = width, height, 0, height
-        for name in ("color", "nd", "motion", "hist_color", "hist_moments", "prev_nd", "t_color", "t_moments",
+        for name in ("color", "nd", "motion", "hist_color", "hist_moments", "hist_len", "prev_nd", "t_color", "t_moments", "t_len",
                      "t_debug", "v_color", "hist_color_out", "out_color"):
             arr = getattr(self, name)
             setattr(d, name, None if arr is None else arr.ctypes.data)
         d.ping[0], d.ping[1] = self.ping[0].ctypes.data, self.ping[1].ctypes.data
+
+    def history(self):
+        """(hist_color, (hist_moments, hist_len), prev_nd) for the next frame's Frame(...)."""
+        return self.hist_color_out, (self.t_moments, self.t_len), self.nd
 
 
 def temporal(fr: Frame, p, row0=0, row1=None):

@@ -61,8 +61,8 @@ def test_two_rank_strong_scaling_bench_runs_without_a_launcher():
     assert d["config"]["frame"] == [7680, 4320] and d["config"]["rows_per_gpu"] == 2160
     assert "configs[3]" in d["config"]["workload"]
     # default for N > 1: one exchange inside the frame (a-trous iteration 3's 32 halo rows); history rows (28, 41] of
-    # hist_color and (33, 41] of hist_moments
+    # hist_color (float4) and (33, 41] of hist_moments (float2) and hist_len (uint8)
     assert d["config"]["exchange_iteration"] == 3
-    assert d["halo_bytes_per_frame_rank0"] == {"history": (13 + 8) * 7680 * 16, "mid_frame": 32 * 7680 * 16}
+    assert d["halo_bytes_per_frame_rank0"] == {"history": 13 * 7680 * 16 + 8 * 7680 * (8 + 1), "mid_frame": 32 * 7680 * 16}
     assert d["cpu_baseline"]["value"] > 0 and d["ms_per_step_median"] > 0
     assert d["value"] > 0 and d["roofline"]["frac"] > 0

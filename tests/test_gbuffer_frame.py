@@ -20,7 +20,7 @@ def test_oracle_composition_of_the_gbuffer_frame(orc):
     render, albedo, normal = (orc.load_cornell(n)[100:228, 150:278].copy() for n in ("render", "albedo", "normal"))
     p = orc.default_params()
     out0, fr0 = orc.gbuffer_frame(render, albedo, normal, p)
-    out1, fr1 = orc.gbuffer_frame(render, albedo, normal, p, hist=(fr0.hist_color_out, fr0.t_moments, fr0.nd))
+    out1, fr1 = orc.gbuffer_frame(render, albedo, normal, p, hist=fr0.history())
     assert out0.dtype == np.uint8 and (out0[..., 3] == 255).all()
     assert abs(out0[..., :3].mean() - render[..., :3].mean()) < 4.0
     rough = lambda a: np.abs(np.diff(a[..., 0].astype(np.int32), axis=1)).mean()      # noqa: E731

@@ -101,7 +101,7 @@ def test_gbuffer_frame_is_the_eight_call_chain_byte_for_byte(rmd, orc, cuda, wid
         assert torch.equal(chain_dbg[f], fused_dbg[f]), f"frame {f}: T's integer outputs differ on {(chain_dbg[f] != fused_dbg[f]).any(-1).sum().item()} pixels"
         assert torch.equal(chain[f], fused[f]), f"frame {f}: {(chain[f] != fused[f]).sum().item()} of {chain[f].numel()} bytes differ"
     # the cross-frame state after the last frame
-    for a, b, name in zip(den_c.history(), den_f.history(), ("hist_color", "hist_moments")):
+    for a, b, name in zip(den_c.history(), den_f.history(), ("hist_color", "hist_moments", "hist_len")):
         assert torch.equal(a, b), f"{name}: {(a != b).sum().item()} values differ"
     if frames > 1 and motion_xy not in (None, (0.0, 0.0)):
         h = fused_dbg[-1][..., 3]
@@ -122,15 +122,15 @@ def test_gbuffer_frame_against_the_oracle_composition(rmd, orc, cuda):
         want, fr = orc.gbuffer_frame(r, albedo, normal, p, hist=hist, albedo_eps=EPS, threads=8)
         got = den.frame(dev(r), dev(albedo), dev(normal)).cpu().numpy()
         assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}: reprojection index / tap mask / history length"
-        hc, hm = (t.cpu().numpy() for t in den.history())
-        assert (hm == fr.t_moments).all(), f"frame {f}: T's float outputs are bit-exact"
+        hc, hm, hl = (t.cpu().numpy() for t in den.history())
+        assert (hm == fr.t_moments).all() and (hl == fr.t_len).all(), f"frame {f}: T's float outputs and the history length are bit-exact"
         err = np.abs(hc.astype(np.float64) - fr.hist_color_out) / (1.0 + np.abs(fr.hist_color_out))
         assert err.max() <= TOL_FRAME, f"frame {f}: hist_color {err.max():.2e}"
         diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
         assert diff.max() <= 1, f"frame {f}: a byte differs by {diff.max()}"
         assert (diff != 0).mean() < 0.005, f"frame {f}: {(diff != 0).mean():.4f} of the bytes differ"
         assert (got[..., 3] == 255).all()
-        hist = (fr.hist_color_out, fr.t_moments, fr.nd)
+        hist = fr.history()
 
 
 @pytest.mark.parametrize("iterations,hist_iteration", [(5, 4), (1, 0), (3, 1), (2, 0), (6, 0)])

@@ -19,9 +19,9 @@ def run_sequence(orc, width, height, inputs, p):
     for i, (c, nd, m) in enumerate(inputs):
         fr = orc.Frame(width, height, c, nd, m, hc, hm, pn)
         orc.frame(fr, p)
-        for k in ("t_color", "t_moments", "t_debug", "v_color", "hist_color_out", "out_color"):
+        for k in ("t_color", "t_moments", "t_len", "t_debug", "v_color", "hist_color_out", "out_color"):
             out[f"f{i}_{k}"] = getattr(fr, k).copy()
-        hc, hm, pn = fr.hist_color_out, fr.t_moments, fr.nd
+        hc, hm, pn = fr.history()
     return out
 
 
@@ -98,22 +98,23 @@ def test_temporal_static_scene_accumulates(orc):
         assert (fr.t_debug[:-1, :-1, 2] == (0 if f == 0 else 15)).all()   # last row/col: +1 taps leave the frame
         if f: assert (fr.t_debug[:-1, -1, 2] == 5).all() and (fr.t_debug[-1, :-1, 2] == 3).all() and fr.t_debug[-1, -1, 2] == 1
         assert (fr.t_debug[..., 0] == np.arange(w)[None, :]).all() and (fr.t_debug[..., 1] == np.arange(h)[:, None]).all()
-        hc, hm, pn = fr.t_color, fr.t_moments, nd
+        hc, hm, pn = fr.t_color, (fr.t_moments, fr.t_len), nd
 
 
 def test_temporal_rejects_out_of_frame_and_far_taps(orc):
     h, w = 12, 12
     nd = np.zeros((h, w, 4), np.float32); nd[..., 2] = 1; nd[..., 3] = 10
     c = np.ones((h, w, 4), np.float32)
-    hist = np.ones((h, w, 4), np.float32); hist[..., 2] = 5
+    hist = np.ones((h, w, 4), np.float32)
+    hist_m = (np.ones((h, w, 2), np.float32), np.full((h, w), 5, np.uint8))          # moments (m1, m2) and history length 5
     p = orc.default_params()
     m = np.zeros((h, w, 2), np.float32); m[..., 0] = -3.0       # reproject 3 px to the left
-    fr = orc.Frame(w, h, c, nd, m, hist, hist, nd)
+    fr = orc.Frame(w, h, c, nd, m, hist, hist_m, nd)
     orc.temporal(fr, p)
     assert (fr.t_debug[:, :3, 3] == 1).all() and (fr.t_debug[:, 3:, 3] == 6).all()
     p.max_motion_rows = 2
     m2 = np.zeros((h, w, 2), np.float32); m2[..., 1] = 4.0      # 4 rows down: beyond max_motion_rows
-    fr = orc.Frame(w, h, c, nd, m2, hist, hist, nd)
+    fr = orc.Frame(w, h, c, nd, m2, hist, hist_m, nd)
     orc.temporal(fr, p)
     assert (fr.t_debug[..., 2] == 0).all() and (fr.t_debug[..., 3] == 1).all()
 
@@ -125,8 +126,8 @@ def test_variance_passes_long_history_through(orc):
     nd = np.zeros((h, w, 4), np.float32); nd[..., 2] = 1; nd[..., 3] = 3
     fr = orc.Frame(w, h, c, nd, np.zeros((h, w, 2), np.float32))
     fr.t_color[:] = c
-    fr.t_moments[..., 2] = 4
-    fr.t_moments[:, :5, 2] = 2
+    fr.t_len[...] = 4
+    fr.t_len[:, :5] = 2
     orc.variance(fr, orc.default_params())
     assert (fr.v_color[:, 5:] == c[:, 5:]).all()
     assert not (fr.v_color[:, :5] == c[:, :5]).all()
@@ -156,9 +157,9 @@ def test_temporal_blend_weights_by_hand(orc):
     orc.temporal(f0, p)
     l0 = float(LUM @ c0[0, 0, :3])
     assert np.allclose(f0.t_color[0, 0], [1, 2, 4, 0], atol=1e-6) and f0.t_debug[0, 0, 3] == 1
-    assert np.allclose(f0.t_moments[0, 0, :3], [l0, l0 * l0, 1], rtol=1e-6)
+    assert np.allclose(f0.t_moments[0, 0], [l0, l0 * l0], rtol=1e-6) and f0.t_len[0, 0] == 1
     c1 = np.array([[[3.0, 2.0, 0.0, 0.0]]], np.float32)
-    f1 = orc.Frame(1, 1, c1, nd, m, f0.t_color, f0.t_moments, nd)
+    f1 = orc.Frame(1, 1, c1, nd, m, f0.t_color, (f0.t_moments, f0.t_len), nd)
     orc.temporal(f1, p)
     l1 = float(LUM @ c1[0, 0, :3])
     m1 = 0.5 * l0 + 0.5 * l1
@@ -166,9 +167,9 @@ def test_temporal_blend_weights_by_hand(orc):
     assert f1.t_debug[0, 0].tolist() == [0, 0, 1, 2]              # q0 = (0,0); only tap (0,0) is inside the frame; h = 2
     assert np.allclose(f1.t_color[0, 0, :3], [2.0, 2.0, 2.0], rtol=1e-6)
     assert abs(f1.t_color[0, 0, 3] - (m2 - m1 * m1)) <= 2e-6 * m2          # fp32 cancellation of two values near 4
-    assert np.allclose(f1.t_moments[0, 0, :3], [m1, m2, 2], rtol=1e-6)
+    assert np.allclose(f1.t_moments[0, 0], [m1, m2], rtol=1e-6) and f1.t_len[0, 0] == 2
     # third frame: h = 3, alpha = 1/3, alpha_m = 1/3
-    f2 = orc.Frame(1, 1, c0, nd, m, f1.t_color, f1.t_moments, nd)
+    f2 = orc.Frame(1, 1, c0, nd, m, f1.t_color, (f1.t_moments, f1.t_len), nd)
     orc.temporal(f2, p)
     assert f2.t_debug[0, 0, 3] == 3
     assert np.allclose(f2.t_color[0, 0, :3], (2.0 * np.array([2, 2, 2]) + np.array([1, 2, 4])) / 3.0, rtol=1e-6)
@@ -179,7 +180,7 @@ def test_temporal_rejects_history_across_a_depth_or_normal_edge_by_hand(orc):
     m = np.zeros((1, 1, 2), np.float32)
     c = np.array([[[1.0, 1.0, 1.0, 0.0]]], np.float32)
     nd_prev = np.array([[[0.0, 0.0, 1.0, 5.0]]], np.float32)
-    hist_m = np.array([[[1.0, 1.0, 7.0, 0.0]]], np.float32)
+    hist_m = (np.array([[[1.0, 1.0]]], np.float32), np.array([[7]], np.uint8))          # (m1, m2), history length 7
     for nd_cur, ok in (([0, 0, 1, 5.05], True),      # |dz| = 0.05 <= k_z (g_z + 1e-2) = 0.1
                        ([0, 0, 1, 5.2], False),      # |dz| = 0.2 > 0.1
                        ([0, 1, 0, 5.0], False)):     # n.n' = 0 < k_n = 0.9
@@ -255,12 +256,11 @@ def test_variance_spatial_estimate_by_hand(orc):
     grey = np.array([[1.0, 2.0, 4.0], [0.5, 1.0, 3.0], [2.0, 2.0, 0.25]], np.float64)
     t_color[..., :3] = grey[..., None].astype(np.float32) * np.array([1.0, 0.5, 2.0], np.float32)   # r, g, b = l', l'/2, 2 l'
     t_color[..., 3] = 0.125
-    t_mom = np.zeros((3, 3, 4), np.float32)
-    t_mom[..., 2] = 4.0                                                    # everybody has a long history ...
-    t_mom[1, 1, 2] = 2.0                                                   # ... except the centre
+    t_len = np.full((3, 3), 4, np.uint8)                                   # everybody has a long history ...
+    t_len[1, 1] = 2                                                        # ... except the centre
     f = orc.Frame(3, 3, t_color, nd, np.zeros((3, 3, 2), np.float32))
     f.t_color[...] = t_color
-    f.t_moments[...] = t_mom
+    f.t_len[...] = t_len
     orc.variance(f, p)
     # by hand, in float64
     gz, zc = 0.25, 4.25

@@ -49,7 +49,7 @@ def test_sends_and_receives_pair_up():
             for _, lo, hi in recvs:
                 assert plans[peer].row0 <= lo and hi <= plans[peer].row1      # sent rows are owned rows
     assert sharding.halo_plan(sharding.make_plan(height, 1, 0, REACH)) == []
-    assert sharding.halo_bytes(plans[1], 3840) == 2 * (13 + 8) * 3840 * 16
+    assert sharding.halo_bytes(plans[1], 3840) == 2 * (13 * 16 + 8 * (8 + 1)) * 3840          # hist_color 16 B/px, hist_moments 8 + hist_len 1
 
 
 REACH_X3 = (34, 41, 28, 33)       # the same with exchange_iteration = 3: T / V / A0..A2 on 32 fewer rows per side
@@ -79,7 +79,7 @@ def test_mid_frame_exchange_plan_pairs_up():
     assert sharding.mid_halo_plan(sharding.make_plan(height, 8, 3, REACH)) == []          # no exchange_iteration: nothing travels
     assert sharding.mid_halo_bytes(plans[1], 7680) == 2 * 32 * 7680 * 16
     assert sharding.mid_halo_bytes(plans[0], 7680) == 32 * 7680 * 16
-    assert sharding.halo_bytes(plans[1], 7680) == 2 * (13 + 8) * 7680 * 16               # history halo: rows (28, 41] and (33, 41]
+    assert sharding.halo_bytes(plans[1], 7680) == 2 * (13 * 16 + 8 * (8 + 1)) * 7680     # history halo: rows (28, 41] of hist_color, (33, 41] of hist_moments + hist_len
     with pytest.raises(ValueError):
         sharding.make_plan(240, 8, 0, (34, 20, 28, 33), MID_X3)                            # 30-row strips < 32 exchanged rows
 
@@ -92,11 +92,18 @@ def _free_port():
     return port
 
 
+PLANE_CHANNELS = {0: 4, 1: 2, 2: 4, 3: 0}          # hist_color float4, hist_moments float2, the mid plane float4, hist_len uint8 [rows, width]
+
+
 def _truth(rows, width, plane_id):
     """What global row y of a plane must contain."""
+    if PLANE_CHANNELS[plane_id] == 0:
+        y = torch.arange(rows[0], rows[1], dtype=torch.int64).view(-1, 1)
+        x = torch.arange(width, dtype=torch.int64).view(1, -1)
+        return ((y * 7 + x * 3 + 1) % 251).to(torch.uint8)
     y = torch.arange(rows[0], rows[1], dtype=torch.float32).view(-1, 1, 1)
     x = torch.arange(width, dtype=torch.float32).view(1, -1, 1)
-    ch = torch.arange(4, dtype=torch.float32).view(1, 1, -1)
+    ch = torch.arange(PLANE_CHANNELS[plane_id], dtype=torch.float32).view(1, 1, -1)
     return y * 1000.0 + x + ch * 0.125 + plane_id * 0.5
 
 
@@ -106,17 +113,17 @@ def _worker(rank, world, port, height, width, result):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         plan = sharding.make_plan(height, world, rank, REACH)
-        planes = []
-        for pid, have in ((0, plan.have_color), (1, plan.have_moments)):
-            t = torch.full((plan.buf_rows, width, 4), -1.0)
+        planes = {}
+        for pid, have in ((0, plan.have_color), (1, plan.have_moments), (3, plan.have_moments)):
+            t = torch.full((plan.buf_rows, width, PLANE_CHANNELS[pid]), -1.0) if PLANE_CHANNELS[pid] else torch.full((plan.buf_rows, width), 255, dtype=torch.uint8)
             lo, hi = max(0, plan.row0 - have), min(height, plan.row1 + have)   # what the rank computed itself
             t[lo - plan.buf_row0:hi - plan.buf_row0] = _truth((lo, hi), width, pid)
-            planes.append(t)
+            planes[pid] = t
         for _ in range(2):                                                   # twice: the exchange is per frame
-            n = sharding.exchange_history_halo(plan, planes[0], planes[1])
+            n = sharding.exchange_history_halo(plan, planes[0], planes[1], planes[3])
         ok = n == len(sharding.halo_plan(plan))
         lo, hi = max(0, plan.row0 - plan.reach_hist), min(height, plan.row1 + plan.reach_hist)
-        for pid, t in enumerate(planes):
+        for pid, t in planes.items():
             ok = ok and torch.equal(t[lo - plan.buf_row0:hi - plan.buf_row0], _truth((lo, hi), width, pid))
         # the mid-frame exchange: a plane that holds only the rank's OWN rows gets the 32 rows on either side
         plan = sharding.make_plan(height, world, rank, REACH_X3, MID_X3)

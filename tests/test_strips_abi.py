@@ -18,11 +18,11 @@ def c_plan(rmd, height, world, rank, p):
 
 
 def c_steps(rmd, plan, fn=None):
-    steps = (HaloStep * 8)()
+    steps = (HaloStep * 12)()                                       # RMD_HALO_MAX_STEPS
     n = C.c_int()
-    rmd.check((fn or lib.rmd_halo_plan)(C.byref(plan), steps, 8, C.byref(n)))
+    rmd.check((fn or lib.rmd_halo_plan)(C.byref(plan), steps, 12, C.byref(n)))
     kind = {HaloStep.RECV: "recv", HaloStep.SEND: "send"}
-    name = {0: "color", 1: "moments", 2: "mid"}
+    name = {0: "color", 1: "moments", 2: "mid", 3: "len"}
     return [(kind[s.kind], name[s.plane], s.row_lo, s.row_hi, s.peer) for s in steps[:n.value]]
 
 
@@ -86,44 +86,48 @@ def test_short_strips_and_bad_arguments_are_rejected(rmd):
     n = C.c_int()
     rmd.check(lib.rmd_strip_plan_make(4320, 8, 3, C.byref(p), C.byref(plan)))
     rmd.check(lib.rmd_halo_plan(C.byref(plan), None, 0, C.byref(n)))                      # counting form
-    assert n.value == 8
+    assert n.value == 12                                                                  # 3 planes x (recv + send) x 2 neighbours
     steps = (HaloStep * 2)()
-    assert lib.rmd_halo_plan(C.byref(plan), steps, 2, C.byref(n)) == -4 and n.value == 8  # RMD_E_BUFFER, count still reported
+    assert lib.rmd_halo_plan(C.byref(plan), steps, 2, C.byref(n)) == -4 and n.value == 12  # RMD_E_BUFFER, count still reported
 
 
 def test_exchange_without_neighbours_needs_no_communicator(rmd):
     p = rmd.default_params()
     plan = c_plan(rmd, 300, 1, 0, p)
-    rmd.check(lib.rmd_halo_exchange(None, C.byref(plan), 64, None, None, None))
+    rmd.check(lib.rmd_halo_exchange(None, C.byref(plan), 64, None, None, None, None))
 
 
 @pytest.mark.gpu
 def test_rccl_loopback_exchange_on_one_gpu(rmd, cuda):
     """ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd through the C ABI with a one-rank communicator:
-    rows [10,14) of hist_color are sent to self into rows [20,24), rows [3,5) of hist_moments into [30,32)."""
+    rows [10,14) of hist_color (float4) are sent to self into rows [20,24), rows [3,5) of hist_moments (float2) into [30,32), and
+    the same rows of hist_len (uint8: travels as bytes)."""
     assert lib.rmd_comm_available() == 1, "librccl.so not found on the GPU box"
     comm = C.c_void_p()
     rmd.check(lib.rmd_comm_create_all(1, None, C.byref(comm)))
     width, rows = 96, 40
     g = torch.Generator(device="cuda").manual_seed(5)
     hc = torch.rand((rows, width, 4), device="cuda", generator=g)
-    hm = torch.rand((rows, width, 4), device="cuda", generator=g)
-    want_c, want_m = hc.clone(), hm.clone()
+    hm = torch.rand((rows, width, 2), device="cuda", generator=g)
+    hl = torch.randint(0, 256, (rows, width), dtype=torch.uint8, device="cuda", generator=g)
+    want_c, want_m, want_l = hc.clone(), hm.clone(), hl.clone()
     want_c[20:24] = hc[10:14]
     want_m[30:32] = hm[3:5]
-    steps = (HaloStep * 4)(HaloStep(HaloStep.RECV, 0, 120, 124, 0), HaloStep(HaloStep.SEND, 0, 110, 114, 0),
-                           HaloStep(HaloStep.RECV, 1, 130, 132, 0), HaloStep(HaloStep.SEND, 1, 103, 105, 0))
+    want_l[30:32] = hl[3:5]
+    steps = (HaloStep * 6)(HaloStep(HaloStep.RECV, 0, 120, 124, 0), HaloStep(HaloStep.SEND, 0, 110, 114, 0),
+                           HaloStep(HaloStep.RECV, 1, 130, 132, 0), HaloStep(HaloStep.SEND, 1, 103, 105, 0),
+                           HaloStep(HaloStep.RECV, HaloStep.PLANE_HIST_LEN, 130, 132, 0), HaloStep(HaloStep.SEND, HaloStep.PLANE_HIST_LEN, 103, 105, 0))
     stream = torch.cuda.current_stream().cuda_stream
-    rmd.check(lib.rmd_halo_exchange_steps(comm, 0, steps, 4, 100, rows, width, hc.data_ptr(), hm.data_ptr(), stream))
+    rmd.check(lib.rmd_halo_exchange_steps(comm, 0, steps, 6, 100, rows, width, hc.data_ptr(), hm.data_ptr(), hl.data_ptr(), stream))
     torch.cuda.synchronize()
-    assert torch.equal(hc, want_c) and torch.equal(hm, want_m)
+    assert torch.equal(hc, want_c) and torch.equal(hm, want_m) and torch.equal(hl, want_l)
     bad = (HaloStep * 1)(HaloStep(HaloStep.SEND, 0, 90, 95, 0))
-    assert lib.rmd_halo_exchange_steps(comm, 0, bad, 1, 100, rows, width, hc.data_ptr(), hm.data_ptr(), stream) == -5
+    assert lib.rmd_halo_exchange_steps(comm, 0, bad, 1, 100, rows, width, hc.data_ptr(), hm.data_ptr(), hl.data_ptr(), stream) == -5
     # the mid-frame plane through the same group: rows [0,4) of an a-trous plane to self into rows [36,40)
     mid = torch.rand((rows, width, 4), device="cuda", generator=g)
     want_mid = mid.clone()
     want_mid[36:40] = mid[0:4]
-    planes = (C.c_void_p * 3)(None, None, mid.data_ptr())
+    planes = (C.c_void_p * 4)(None, None, mid.data_ptr(), None)
     msteps = (HaloStep * 2)(HaloStep(HaloStep.RECV, HaloStep.PLANE_MID, 136, 140, 0), HaloStep(HaloStep.SEND, HaloStep.PLANE_MID, 100, 104, 0))
     rmd.check(lib.rmd_exchange_steps(comm, 0, msteps, 2, 100, rows, width, planes, stream))
     torch.cuda.synchronize()

@@ -32,9 +32,11 @@ def dev(a):
 
 def gpu_frame_desc(rmd, fr, **over):
     """Device copy of an oracle Frame's inputs + fresh output planes, and the descriptor."""
-    t = {k: dev(getattr(fr, k)) for k in ("color", "nd", "motion", "hist_color", "hist_moments", "prev_nd")}
-    for k in ("t_color", "t_moments", "v_color", "hist_color_out", "out_color"):
+    t = {k: dev(getattr(fr, k)) for k in ("color", "nd", "motion", "hist_color", "hist_moments", "hist_len", "prev_nd")}
+    for k in ("t_color", "v_color", "hist_color_out", "out_color"):
         t[k] = torch.zeros((fr.height, fr.width, 4), dtype=torch.float32, device="cuda")
+    t["t_moments"] = torch.zeros((fr.height, fr.width, 2), dtype=torch.float32, device="cuda")        # float2 (m1, m2)
+    t["t_len"] = torch.zeros((fr.height, fr.width), dtype=torch.uint8, device="cuda")                 # history length
     t["t_debug"] = torch.zeros((fr.height, fr.width, 4), dtype=torch.int32, device="cuda")
     t.update(over)
     ping = (torch.zeros_like(t["t_color"]), torch.zeros_like(t["t_color"]))
@@ -50,7 +52,7 @@ def oracle_sequence(orc, width, height, frames, p, inputs=None):
         fr = orc.Frame(width, height, c, nd, m, hc, hm, pn)
         orc.frame(fr, p, threads=8)
         out.append(fr)
-        hc, hm, pn = fr.hist_color_out, fr.t_moments, fr.nd
+        hc, hm, pn = fr.history()
     return out
 
 
@@ -68,6 +70,7 @@ def test_temporal_bit_exact(rmd, orc, cuda, width, height):
         assert (dbg == fr.t_debug).all(), f"frame {f}: q0/mask/h differ at {np.argwhere(dbg != fr.t_debug)[:4]}"
         assert (t["t_color"].cpu().numpy() == fr.t_color).all(), f"frame {f}: t_color not bit-exact"
         assert (t["t_moments"].cpu().numpy() == fr.t_moments).all(), f"frame {f}: t_moments not bit-exact"
+        assert (t["t_len"].cpu().numpy() == fr.t_len).all(), f"frame {f}: history length plane"
         if f > 0:
             assert (dbg[..., 2] != 0).any() and (dbg[..., 3] > 1).any()      # history really used
             assert (dbg[..., 3] == 1).any()                                  # and disocclusions exist
@@ -89,13 +92,13 @@ def test_temporal_row_range_and_motion_limit(rmd, orc, cuda):
 def test_variance_parity(rmd, orc, cuda, width, height):
     p = rmd.default_params()
     for f, fr in enumerate(oracle_sequence(orc, width, height, 2, p)):
-        d, t, _ = gpu_frame_desc(rmd, fr, t_color=dev(fr.t_color), t_moments=dev(fr.t_moments))
+        d, t, _ = gpu_frame_desc(rmd, fr, t_color=dev(fr.t_color), t_moments=dev(fr.t_moments), t_len=dev(fr.t_len))
         stats = torch.zeros(4, device="cuda")
         d.stats = stats.data_ptr()
         rmd.svgf.variance(d, p, 0, height)
         torch.cuda.synchronize()
         close(t["v_color"], fr.v_color, TOL_PASS, f"v_color frame {f}")
-        h = fr.t_moments[..., 2]
+        h = fr.t_len.astype(np.float64)
         spatial = h < p.var_h_threshold
         # pass-through pixels are copied bit for bit
         assert (t["v_color"].cpu().numpy()[~spatial] == fr.t_color[~spatial]).all()
@@ -239,9 +242,9 @@ def test_full_frame_sequence_vs_oracle_and_golden(rmd, orc, cuda):
         assert (den.t_debug.cpu().numpy() == golden[f"synth_f{f}_t_debug"]).all()
         close(out, fr.out_color, TOL_FRAME, f"frame {f} out_color")
         close(out, golden[f"synth_f{f}_out_color"], TOL_FRAME, f"frame {f} out_color vs golden")
-        hc, hm = den.history()
+        hc, hm, hl = den.history()
         close(hc, fr.hist_color_out, TOL_FRAME, f"frame {f} hist_color")
-        close(hm, fr.t_moments, TOL_FRAME, f"frame {f} hist_moments")
+        assert (hm.cpu().numpy() == fr.t_moments).all() and (hl.cpu().numpy() == fr.t_len).all(), f"frame {f}: T's moments / history length (bit-exact)"
 
 
 NON_DEFAULT = [
@@ -328,9 +331,9 @@ def test_full_frames_with_non_default_parameters(rmd, orc, cuda, over):
         torch.cuda.synchronize()
         assert (den.t_debug.cpu().numpy() == fr.t_debug).all(), f"frame {f}: integer outputs"
         close(out, fr.out_color, TOL_FRAME, f"frame {f} out_color {over}")
-        hc, hm = den.history()
+        hc, hm, hl = den.history()
         close(hc, fr.hist_color_out, TOL_FRAME, f"frame {f} hist_color {over}")
-        close(hm, fr.t_moments, TOL_FRAME, f"frame {f} hist_moments {over}")
+        assert (hm.cpu().numpy() == fr.t_moments).all() and (hl.cpu().numpy() == fr.t_len).all(), f"frame {f}: T's moments / history length {over}"
 
 
 def test_cornell_full_svgf(rmd, orc, cuda):
@@ -466,12 +469,12 @@ def simulate_strips(rmd, width, height, world, frames, p):
             r.den.has_history, r.den.prev_nd = True, nd
             full[r.plan.row0:r.plan.row1] = o[r.plan.row0 - r.plan.buf_row0:r.plan.row1 - r.plan.buf_row0]
         for r in ranks:                                   # the history exchange, by plan
-            hist = dict(zip(("color", "moments"), r.den.history()))
+            hist = dict(zip(("color", "moments", "len"), r.den.history()))
             for kind, name, lo, hi, peer in sharding.halo_plan(r.plan):
                 if kind != "recv":
                     continue
                 q = ranks[peer]
-                src = dict(zip(("color", "moments"), q.den.history()))[name]
+                src = dict(zip(("color", "moments", "len"), q.den.history()))[name]
                 assert q.plan.row0 <= lo and hi <= q.plan.row1, "a halo row must come from its owner"
                 hist[name][lo - r.plan.buf_row0:hi - r.plan.buf_row0] = src[lo - q.plan.buf_row0:hi - q.plan.buf_row0]
         outs.append(full)

@@ -42,7 +42,7 @@ for it in range(5):
         frac = np.median(phs / np.maximum(tot, 1), axis=0)
         if p.atrous_variant == 7:      # loader/consumer kernel: cycles, not fractions
             ph8 = buf[NWG * 6:].reshape(NWG, 8)[rec[:, 0] > 0].astype(np.float64)
-            rows8 = np.maximum(rec[rec[:, 0] > 0][:, 5].astype(np.float64), 1)
+            rows8 = np.maximum((rec[rec[:, 0] > 0][:, 5] & 0xFFFFFFFF).astype(np.float64), 1)
             med = np.median(ph8 / rows8[:, None], axis=0) * 12
             print("    cycles per step (12 lattice rows), median: consumer 0 wait %.0f compute %.0f loads+stores %.0f | consumer 11 wait %.0f compute %.0f"
                   " | loader wait-for-slot %.0f commit %.0f issue %.0f" % tuple(med))
@@ -73,7 +73,7 @@ for it in range(5):
     print(f"    per-CU last end us: p10 {np.percentile(cu_end, 10):.1f}  p50 {np.percentile(cu_end, 50):.1f}  p90 {np.percentile(cu_end, 90):.1f}  max {cu_end.max():.1f}")
     late = start > np.percentile(end, 10)
     print(f"    workgroups that start after the first 10% have ended: {late.sum()}")
-    cyc, rows = t[:, 4].astype(np.float64), t[:, 5].astype(np.float64)
+    cyc, rows = t[:, 4].astype(np.float64), (t[:, 5] & 0xFFFFFFFF).astype(np.float64)
     ghz = cyc / np.maximum(dur, 1) * 0.1
     sel = ~edge
     print(f"    shader clock while resident: p50 {np.percentile(ghz, 50):.2f} GHz (p10 {np.percentile(ghz, 10):.2f}, p90 {np.percentile(ghz, 90):.2f}); "

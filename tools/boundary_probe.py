@@ -90,8 +90,8 @@ for rep in range(REPS + 2):
             src = dst
         assert raw.rmd_debug_atrous_trace(buf.ctypes.data_as(C.c_void_p), NWG) == 0       # synchronises; the LAST launch's records
         rec = buf.reshape(NWG, 6)
-        t = rec[rec[:, 0] > 0]
-        if rep >= 2:
+        t = rec[(rec[:, 0] > 0) & ((rec[:, 5] >> 32) == (1 << it))]       # the last launch's own records (a record is keyed by workgroup id:
+        if rep >= 2:                                                         # an earlier launch with more workgroups leaves some behind)
             spans[str(it)].append(float(t[:, 1].max() - t[:, 0].min()) / 100.0)
 json.dump({"reps": REPS, "nt_out": os.environ.get("RMD_NT_OUT", "default (on at 4K)"), "span_us": spans},
           open(os.environ.get("PROBE_OUT", "spans.json"), "w"))

@@ -21,7 +21,7 @@ f0 = orc.Frame(w, h, c, nd, m, None, None, None, debug=False)
 orc.frame(f0, p, threads=16)
 c1, nd1, m1 = orc.synth_gbuffer(w, h, 1)
 for threads in (8, 16, 32, 64, 128, 256):
-    f1 = orc.Frame(w, h, c1, nd1, m1, f0.hist_color_out, f0.t_moments, f0.nd, debug=False)
+    f1 = orc.Frame(w, h, c1, nd1, m1, *f0.history(), debug=False)
     t0 = time.perf_counter()
     orc.frame(f1, p, threads=threads)
     dt = time.perf_counter() - t0

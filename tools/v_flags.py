@@ -17,7 +17,7 @@ for f in range(10):
     torch.cuda.synchronize()
     tx, ty = (W + 63) // 64, (H + 3) // 4
     fl = den.tile_flags[:tx * ty].reshape(ty, tx).cpu().numpy() != 0
-    hist = den.hist_moments[den.cur][..., 2]
+    hist = den.hist_len[den.cur]
     short = (hist < p.var_h_threshold).sum().item()
     cols = fl.sum(axis=0)
     print(f"frame {f}: flagged tiles {fl.sum()} of {fl.size}; short-history pixels {short}; flagged per tile column: "
