@@ -266,6 +266,51 @@ def cornell_u8_sequence(torch, width, height, nframes, pan, seed=2024):
     return seq
 
 
+def pcie_streaming(rmd, torch, gden, seq, motion, frames, warm, host_frames=8):
+    """uchar4 planes in pinned HOST memory -> H2D -> rmd_svgf_gbuffer_frame -> D2H of `denoised`, software-pipelined: two device
+    GBuffers, the uploads on one stream, the frames on torch's current stream, the downloads on a third, ordered by events.  In
+    the steady state a frame costs max(upload of 12 B/px, the frame, download of 4 B/px); at 4K the upload (100 MB per frame
+    over the host link) is the longest of the three."""
+    host = [tuple(t.cpu().pin_memory() for t in fr) for fr in seq[:host_frames]]
+    h, w = seq[0][0].shape[:2]
+    dev_in = [tuple(torch.empty_like(seq[0][0]) for _ in range(3)) for _ in range(2)]
+    dev_out = [torch.empty_like(seq[0][0]) for _ in range(2)]
+    host_out = [torch.empty(seq[0][0].shape, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    main, up, down = torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    ev_up, ev_done, ev_down = ([torch.cuda.Event() for _ in range(2)] for _ in range(3))
+    gden.reset_history()
+
+    def frame(f):
+        k = f & 1
+        with torch.cuda.stream(up):
+            up.wait_event(ev_done[k])                    # the frame that last read these device planes (f - 2) is done
+            for dst, src in zip(dev_in[k], host[f % host_frames]):
+                dst.copy_(src, non_blocking=True)
+            ev_up[k].record(up)
+        main.wait_event(ev_up[k])
+        main.wait_event(ev_down[k])                      # the download of frame f - 2 has left dev_out[k]
+        gden.frame(dev_in[k][0], dev_in[k][1], dev_in[k][2], dev_out[k], motion)
+        ev_done[k].record(main)
+        with torch.cuda.stream(down):
+            down.wait_event(ev_done[k])
+            host_out[k].copy_(dev_out[k], non_blocking=True)
+            ev_down[k].record(down)
+
+    for f in range(warm):
+        frame(f)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(warm, warm + frames):
+        frame(f)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    px = w * h
+    return {"fps": round(frames / dt, 1), "ms_per_frame": round(dt / frames * 1e3, 4), "mpix_s": round(px * frames / dt / 1e6, 1),
+            "h2d_GBps": round(12.0 * px * frames / dt / 1e9, 1), "d2h_GBps": round(4.0 * px * frames / dt / 1e9, 1),
+            "what": "pinned host uchar4 planes -> H2D (12 B/px) -> one-call frame -> D2H of denoised (4 B/px); 3 streams, 2 device GBuffers",
+            "last_frame_mean_u8": round(float(host_out[(warm + frames - 1) & 1][..., :3].float().mean()), 2)}
+
+
 def cornell_sequence(rmd, torch, p, width=3840, height=2160, frames=60, warm=6, pan=(2.25, 1.5)):
     """BASELINE configs[4]: a 60-frame 4K animated Cornell sequence, steady-state frames per second, in three forms over the
     SAME resident frames:
@@ -305,6 +350,10 @@ def cornell_sequence(rmd, torch, p, width=3840, height=2160, frames=60, warm=6, 
     out_fused = torch.empty_like(seq[0][0])
     fused = clock(lambda f: gden.frame(seq[f][0], seq[f][1], seq[f][2], out_fused, motion), gden.reset_history)
     fused["launches_per_frame"] = 6
+    # --- the same call with the frames coming from and going back to HOST memory (the CudaGBuffer::openImages direction of the
+    # boundary, include/gbuffer.h:20-33): pinned host planes, double-buffered device GBuffers, uploads / the frame / the
+    # download on three streams.  NOT `value` (inputs resident is the contract); the PCIe-inclusive rate DESIGN.md quotes.
+    pcie = pcie_streaming(rmd, torch, gden, seq, motion, frames, warm)
     del gden
     # --- unfused: the eight-call chain on the same bytes
     den = rmd.SvgfDenoiser(width, height, params=p)
@@ -342,6 +391,7 @@ def cornell_sequence(rmd, torch, p, width=3840, height=2160, frames=60, warm=6, 
             "frames": frames,
             "end_to_end_u8": {"fused": fused, "unfused": unfused, "last_frame_bytes_identical": same,
                               "fused_over_unfused": round(fused["fps"] / unfused["fps"], 3)},
+            "pcie_inclusive_u8": pcie,
             "float_planes": floats, "fused_u8_over_float_planes": round(fused["fps"] / floats["fps"], 3),
             # (kept under the old keys: the figure comparable with round 3's cornell_sequence_4k)
             "fps": fused["fps"], "ms_per_frame": fused["ms_per_frame"], "mpix_s": fused["mpix_s"],
@@ -585,6 +635,8 @@ def main():
                                  for w, h, n, wu in ((1920, 1080, 48, 8), (7680, 4320, 16, 4))}
         result["reference_api"] = reference_api_kernels(rmd, torch)
         result["cornell_sequence_4k"] = cornell_sequence(rmd, torch, p)       # BASELINE configs[4]
+        torch.cuda.empty_cache()
+        result["cornell_1080p"] = cornell_sequence(rmd, torch, p, width=1920, height=1080)      # BASELINE configs[1]: 1920x1080 Cornell, full SVGF
     if world > 1 and rank == 0 and not args.no_other_sizes:
         # the SAME 8K frame unsharded on rank 0's GPU: what the N-GPU figure is a speed-up over
         del frames, sd

@@ -777,9 +777,11 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         if constexpr (OUT8) {
             // modulate by the albedo, quantise, store bytes: rmd_convert_f32_to_u8's arithmetic on the registers of finish()
             if (xin) {
-                auto al = [&](const unsigned v) { return float4_from_u8(make_uchar4(v & 255u, (v >> 8) & 255u, (v >> 16) & 255u, v >> 24), false, 0.0f); };
-                if (jw >= jlo && jw < jhi) (a.out8 + row_base(yA, x0))[col] = u8_from_float4(outA, true, al(pa8[0]));
-                if (jw + 1 >= jlo && jw + 1 < jhi) (a.out8 + row_base(yA + S, x0))[col] = u8_from_float4(outB, true, al(pa8[1]));
+                unsigned bA, bB;
+                u8_pair_modulated(outA, outB, pa8[0], pa8[1], bA, bB);          // both pixels at once, packed (pixel_convert.h)
+                unsigned* const o32 = reinterpret_cast<unsigned*>(a.out8);
+                if (jw >= jlo && jw < jhi) (o32 + row_base(yA, x0))[col] = bA;
+                if (jw + 1 >= jlo && jw + 1 < jhi) (o32 + row_base(yA + S, x0))[col] = bB;
             }
         } else if (xin) {
             // Non-temporal stores: the 133 MB a 4K launch writes are the expensive third of its traffic (the

@@ -80,6 +80,27 @@ def test_u8_to_unit_float_on_the_device_is_the_ieee_quotient(rmd, cuda):
     assert (got.view(np.uint32) == want.view(np.uint32)).all()
 
 
+def test_quantisation_special_values(rmd, orc, cuda):
+    """rmd_convert_f32_to_u8 (csrc/pixel_convert.h: v_floor_f32 + v_cvt_pk_u8_f32, shared with the last a-trous launch of
+    rmd_svgf_gbuffer_frame) against the oracle's C cast chain on everything the clamp has to catch: NaN, +-inf, negatives, values
+    above 1, and every k/255 +- 1 ulp (the rounding boundaries of x * 255 + 0.5)."""
+    k = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    edge = np.concatenate([k, np.nextafter(k, np.float32(2)), np.nextafter(k, np.float32(-1)),
+                           (np.arange(256, dtype=np.float32) + np.float32(0.5)) / np.float32(255.0)])
+    special = np.array([np.nan, np.inf, -np.inf, -0.0, 0.0, -1e-30, 1e-30, -5.0, 1.0, 1.0000001, 7.0, 3e38, -3e38, 0.00196, 0.99804], np.float32)
+    vals = np.concatenate([edge, special]).astype(np.float32)
+    n = (len(vals) + 2) // 3 * 3
+    vals = np.resize(vals, n)
+    img = np.zeros((1, n, 4), np.float32)
+    img[0, :, 0], img[0, :, 1], img[0, :, 2] = vals, np.roll(vals, 1), np.roll(vals, 2)
+    with np.errstate(invalid="ignore"):
+        want = orc.convert_f32_to_u8(img)
+    got = rmd.svgf.convert_f32_to_u8(dev(img)).cpu().numpy()
+    assert (got == want).all(), np.argwhere(got != want)[:5]
+    alb = np.full((1, n, 4), 0.5, np.float32)
+    assert (rmd.svgf.convert_f32_to_u8(dev(img), dev(alb)).cpu().numpy() == orc.convert_f32_to_u8(img, alb)).all()
+
+
 @pytest.mark.parametrize("width,height,frames,pan,motion_xy", [
     (500, 500, 3, (0, 0), None),                 # the fixture itself, static camera, motion = NULL
     (500, 500, 3, (0, 0), (0.0, 0.0)),           # the same with an explicit zero motion plane

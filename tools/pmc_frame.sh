@@ -10,4 +10,4 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d "$OUT" -o pass$i -- python3 "$R/bench.py" --no-cpu-baseline --no-other-sizes --steps 20 --warmup 8 > "$OUT/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -3 "$OUT/pass$i.log"; }
 done
-python3 "$R/tools/pmc_summary.py" "$OUT" --all
+python3 "$R/tools/pmc_summary.py" "$OUT" --all --median

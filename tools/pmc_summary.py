@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Reduces rocprofv3 --pmc CSVs (tools/pmc_passes.sh) to per-kernel averages.
-usage: tools/pmc_summary.py <dir> [--json out.json]"""
+usage: tools/pmc_summary.py <dir> [--all] [--median] [--json out.json]"""
 import csv, glob, json, os, sys, collections
 
 d = sys.argv[1]
@@ -20,6 +20,11 @@ for k in sorted(acc):
         continue
     vals = {c: sum(v) / len(v) for c, v in acc[k].items()}
     vals["dur_us(profiled)"] = sum(dur[k]) / max(1, len(dur[k]))
+    if "--median" in sys.argv:          # frame loops: the warm-up frames (no history: V everywhere) are in the means, not in the medians
+        for c, v in acc[k].items():
+            vals[c + " (median)"] = sorted(v)[len(v) // 2]
+        if dur[k]:
+            vals["dur_us(profiled) (median)"] = sorted(dur[k])[len(dur[k]) // 2]
     out[k] = vals
     print(k)
     for c, v in sorted(vals.items()):
