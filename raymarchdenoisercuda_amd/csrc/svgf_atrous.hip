@@ -17,7 +17,9 @@
 //            step; NP = 1: 256 columns x 2 rows).  A ring of 2NP+4 lattice rows (width
 //            256/NP + 4S) lives in LDS, so every input row is fetched from L2/HBM once per
 //            strip as 16-byte-per-lane coalesced segments and each of the 25 taps is a
-//            conflict-free ds_read_b128 with an immediate offset.  Each thread produces two
+//            conflict-free ds_read_b128 with an immediate offset (the per-pixel setup's ds_read_b32
+//            of the neighbours' .w at a 16-byte stride are not: 15 % of the LDS cycles are bank
+//            conflicts, profiles/r03_atrous_pmc.txt; LDS is not what bounds the pass).  Each thread produces two
 //            vertically adjacent lattice pixels (A, B) per step: 30 tap fetches serve 50 weight
 //            evaluations, and the 40 evaluations whose tap both pixels share run their cosine
 //            and their five accumulations as PACKED f32 (v_pk_fma_f32 / v_pk_mul_f32 /

@@ -27,6 +27,9 @@ struct FusedVArgs {
     int h_threshold;
     float sigma_n, sigma_z;
     int tiles_x, tiles_y;     // the launch's tile grid (one workgroup per tile, dealt out edges first)
+#ifdef RMD_EXPERIMENTS
+    int xcd_group;            // > 0: the interior tiles in XCD-owned column groups of this many tile columns (below; measured slower); 0: row by row
+#endif
 };
 
 // IN8 (rmd_svgf_gbuffer_frame): the same launch with the 8-bit front end of temporal_pixel<true> -- the workgroup reads the
@@ -52,7 +55,39 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
         else if (id < 2 * nx)               { bx = id - nx; by = 0; }
         else if (id < 2 * nx + (ny - 2))    { bx = 0; by = 1 + id - 2 * nx; }
         else if (id < 2 * nx + 2 * (ny - 2)) { bx = nx - 1; by = 1 + id - 2 * nx - (ny - 2); }
+#ifndef RMD_EXPERIMENTS
         else { const int k = id - 2 * nx - 2 * (ny - 2); bx = 1 + k % (nx - 2); by = 1 + k / (nx - 2); }
+#else
+        else if (v.xcd_group <= 0) { const int k = id - 2 * nx - 2 * (ny - 2); bx = 1 + k % (nx - 2); by = 1 + k / (nx - 2); }
+        else {
+            // EXPERIMENTS BUILD (RMD_TV_XCD_GROUP=G; measured and lost, DESIGN.md section 4.6: 4K 169-170 us row by row against 183-199 for
+            // G = 1 ... 16, tools/tv_probe.py).  The interior, XCD-aware.  A 64x4 tile shares rows with the tiles above and below it: its reprojection taps reach one
+            // history row beyond its own four, its depth gradient one nd row -- a quarter of the 41 + 16 bytes per pixel of those
+            // planes.  Dealt out row by row, vertical neighbours are nx ids apart and land on different XCDs (workgroup id % 8), so
+            // every shared row is fetched twice from the fabric: the counters show 894 MB read per 4K launch against 672
+            // algorithmic (profiles/r04_pmc_frame.txt).  Here the interior is ONE sequence Q in column-group-major order (groups of
+            // xcd_group tile columns, row-major inside a group), cut into eight contiguous runs of (almost) equal length, one per
+            // XCD: the workgroups id, id + 8, id + 16 ... of an XCD walk down ITS run, so a tile and the tile below it run on the
+            // same XCD xcd_group positions apart and the shared rows hit its L2.  Every XCD has the same number of tiles (no tail), and a
+            // group row is xcd_group KB of contiguous addresses per plane row.
+            const int first = 2 * nx + 2 * (ny - 2), total = nx * ny, wi = nx - 2, hi = ny - 2;
+            const int xcd = id & (kXcds - 1);
+            int start = 0, len = 0;
+            for (int j = 0; j < kXcds; ++j) {                       // interior ids with residue j: first_j, first_j + 8, ...
+                const int first_j = first + ((j - first) & (kXcds - 1));
+                const int len_j = first_j < total ? (total - first_j + kXcds - 1) / kXcds : 0;
+                if (j < xcd) start += len_j;
+                if (j == xcd) len = len_j;
+            }
+            const int first_x = first + ((xcd - first) & (kXcds - 1));
+            const int q = start + (id - first_x) / kXcds;           // position in Q
+            const int G = v.xcd_group, per_group = G * hi;
+            const int grp = q / per_group, r = q - grp * per_group;
+            const int gw = min(G, wi - grp * G);                    // (the last group may be narrower)
+            bx = 1 + grp * G + r % gw;
+            by = 1 + r / gw;
+        }
+#endif
     }
     const int tile_x = bx, tile_y = a.row0 / 4 + by;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
@@ -314,6 +349,9 @@ int rmd::launch_temporal_variance(const rmd_svgf_frame_desc* f, const rmd_svgf_p
     a.h_max = p->h_max; a.max_motion_rows = p->max_motion_rows;
     const int tiles_x = (f->width + 63) / 64, tiles_y = (row1 - 1) / 4 - row0 / 4 + 1;
     FusedVArgs v = { v_row0, v_row1, p->var_h_threshold, p->sigma_n, p->sigma_z, tiles_x, tiles_y };
+#ifdef RMD_EXPERIMENTS
+    v.xcd_group = tuning_env("RMD_TV_XCD_GROUP", 0);       // A/B knob of tools/tv_probe.py
+#endif
     const dim3 grid((unsigned)tiles_x * (unsigned)tiles_y);
     if (g8) hipLaunchKernelGGL(HIP_KERNEL_NAME(svgf_temporal_variance_kernel<true>), grid, dim3(256), 0, as_stream(stream), a, v);
     else    hipLaunchKernelGGL(HIP_KERNEL_NAME(svgf_temporal_variance_kernel<false>), grid, dim3(256), 0, as_stream(stream), a, v);

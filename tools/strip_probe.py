@@ -69,7 +69,7 @@ if os.environ.get("PROBE_LOOPBACK") == "1":
     stream = torch.cuda.current_stream().cuda_stream
 
     def once():
-        rmd.check(lib.rmd_halo_exchange_steps(comm, 0, steps, 2, 0, 4 * rows, W, plane.data_ptr(), plane.data_ptr(), stream))
+        rmd.check(lib.rmd_halo_exchange_steps(comm, 0, steps, 2, 0, 4 * rows, W, plane.data_ptr(), None, None, stream))
     for _ in range(5):
         once()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
