@@ -135,10 +135,10 @@ extern "C" {
 
 const char* rmd_last_error_string(void) { return g_err; }
 #ifdef RMD_EXPERIMENTS
-const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.3 (gfx950, experiments build)"; }
+const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.4 (gfx950, experiments build)"; }
 int rmd_has_experiments(void) { return 1; }
 #else
-const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.3 (gfx950)"; }
+const char* rmd_version(void) { return "raymarchdenoisercuda_amd 0.4 (gfx950)"; }
 int rmd_has_experiments(void) { return 0; }
 #endif
 
