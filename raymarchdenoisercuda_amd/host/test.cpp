@@ -413,6 +413,82 @@ TEST(FRAME_GRAPH)
     rmdCheck(rmd_stream_destroy(stream), "stream");
 }
 
+// ---- the one call with its frames coming from and going back to HOST memory, through the C ABI only ----------------------
+// (the direction CudaGBuffer::openImages is the declared hook for, reference include/gbuffer.h:20-33).  Pinned host planes, two device
+// GBuffers, uploads / frames / downloads on three streams ordered by events: a frame costs max(upload of 12 B/px, the frame, download of
+// 4 B/px) once the pipeline is full.  The streamed frames must give the bytes the same frames give when they are resident.
+TEST(SVGF_STREAM_4K)
+{
+    const int W = 3840, H = 2160, hostFrames = 4, frames = 24;
+    const size_t n = (size_t)W * H;
+    // 8-bit frames on the host: the Cornell planes tiled to 4K, the render modulated per frame (a deterministic pattern)
+    Image render(dataPath() + "render.png", 4), albedo(dataPath() + "albedo.png", 4), normal(dataPath() + "normal.png", 4);
+    const int tw = render.shape.x, th = render.shape.y;
+    byte* host[hostFrames][3];
+    byte* hostOut[2];
+    for (int f = 0; f < hostFrames; ++f)
+        for (int k = 0; k < 3; ++k) rmdCheck(rmd_host_alloc_pinned((void**)&host[f][k], 4 * n), "pinned input");
+    for (int k = 0; k < 2; ++k) rmdCheck(rmd_host_alloc_pinned((void**)&hostOut[k], 4 * n), "pinned output");
+    const Image* src[3] = { &render, &albedo, &normal };
+    for (int f = 0; f < hostFrames; ++f)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                const size_t t = ((size_t)(y % th) * tw + (x % tw)) * 4, i = ((size_t)y * W + x) * 4;
+                const unsigned gain = 192 + ((unsigned)(x * 7 + y * 13 + f * 29) & 63);          // 0.75 .. 1.0 in 1/256
+                for (int c = 0; c < 4; ++c) {
+                    host[f][0][i + c] = c < 3 ? (byte)((src[0]->data[t + c] * gain) >> 8) : 255;
+                    host[f][1][i + c] = src[1]->data[t + c];
+                    host[f][2][i + c] = src[2]->data[t + c];
+                }
+            }
+    CudaVector<uchar4> in[2][3] = { { CudaVector<uchar4>(n), CudaVector<uchar4>(n), CudaVector<uchar4>(n) },
+                                    { CudaVector<uchar4>(n), CudaVector<uchar4>(n), CudaVector<uchar4>(n) } };
+    CudaVector<uchar4> out[2] = { CudaVector<uchar4>(n), CudaVector<uchar4>(n) };
+    void *main_s, *up, *down, *evUp[2], *evDone[2], *evDown[2];
+    rmdCheck(rmd_stream_create(&main_s), "stream"); rmdCheck(rmd_stream_create(&up), "stream"); rmdCheck(rmd_stream_create(&down), "stream");
+    for (int k = 0; k < 2; ++k) { rmdCheck(rmd_event_create(&evUp[k]), "event"); rmdCheck(rmd_event_create(&evDone[k]), "event"); rmdCheck(rmd_event_create(&evDown[k]), "event"); }
+    const SvgfParams p = svgfDefaultParams();
+    auto gbuffer = [&](int k) {
+        GBuffer g = {};
+        g.shape = int2{ W, H }; g.render = in[k][0].data(); g.albedo = in[k][1].data(); g.normal = in[k][2].data(); g.denoised = out[k].data();
+        return g;
+    };
+    // resident reference: the same frames uploaded first, one stream
+    CpuVector<uchar4> want(n);
+    {
+        SvgfContext ctx(W, H);
+        for (int f = 0; f < frames; ++f) {
+            for (int c = 0; c < 3; ++c) rmdCheck(rmd_memcpy_h2d(in[0][c].data(), host[f % hostFrames][c], 4 * n), "upload");
+            svgfDenoise(gbuffer(0), ctx, p);
+        }
+        out[0].copyTo(want);
+    }
+    SvgfContext ctx(W, H);
+    auto frame = [&](int f, bool recorded) {
+        const int k = f & 1;
+        if (recorded) rmdCheck(rmd_stream_wait_event(up, evDone[k]), "wait");           // frame f - 2 is done with these device planes
+        for (int c = 0; c < 3; ++c) rmdCheck(rmd_memcpy_h2d_async(in[k][c].data(), host[f % hostFrames][c], 4 * n, up), "upload");
+        rmdCheck(rmd_event_record(evUp[k], up), "record");
+        rmdCheck(rmd_stream_wait_event(main_s, evUp[k]), "wait");
+        if (recorded) rmdCheck(rmd_stream_wait_event(main_s, evDown[k]), "wait");       // the download of frame f - 2 has left out[k]
+        svgfDenoise(gbuffer(k), ctx, p, nullptr, 1.0f / 255.0f, main_s);
+        rmdCheck(rmd_event_record(evDone[k], main_s), "record");
+        rmdCheck(rmd_stream_wait_event(down, evDone[k]), "wait");
+        rmdCheck(rmd_memcpy_d2h_async(hostOut[k], out[k].data(), 4 * n, down), "download");
+        rmdCheck(rmd_event_record(evDown[k], down), "record");
+    };
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (int f = 0; f < frames; ++f) frame(f, f >= 2);
+    rmdCheck(rmd_stream_sync(main_s), "sync"); rmdCheck(rmd_stream_sync(down), "sync"); rmdCheck(rmd_stream_sync(up), "sync");
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::high_resolution_clock::now() - t0).count() / frames;
+    printf("streamed 8-bit SVGF 3840x2160: %.3f ms per frame = %.0f frames/s (H2D %.1f GB/s, D2H %.1f GB/s; pipeline fill included)\n", ms, 1e3 / ms,
+           12.0 * n / ms / 1e6, 4.0 * n / ms / 1e6);
+    expect(memcmp(hostOut[(frames - 1) & 1], want.data(), 4 * n) == 0, "the streamed frames give the bytes of the resident frames");
+    for (int k = 0; k < 2; ++k) { rmd_event_destroy(evUp[k]); rmd_event_destroy(evDone[k]); rmd_event_destroy(evDown[k]); rmd_host_free_pinned(hostOut[k]); }
+    for (int f = 0; f < hostFrames; ++f) for (int k = 0; k < 3; ++k) rmd_host_free_pinned(host[f][k]);
+    rmd_stream_destroy(main_s); rmd_stream_destroy(up); rmd_stream_destroy(down);
+}
+
 // ---- full SVGF at 4K on the synthetic scene (BASELINE config 3), timed with HIP events -------
 // The G-buffers of all frames are generated first and stay resident; the timed frames are issued
 // back to back on the default stream between ONE pair of events (a sync per frame would time the

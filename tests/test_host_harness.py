@@ -60,10 +60,11 @@ def test_reference_main_cpp_compiles_against_our_headers(tmp_path):
 @pytest.mark.gpu
 def test_every_harness_test_passes_on_the_gpu():
     """DEVICE_STATS, FILTER_BASELINE, FILTER_TILED, FILTER_CORNELL (SHA-256 known answers through
-    filterKernelBaseline / filterKernelTiled), IMAGE, VECTOR, SVGF_CORNELL (openImages upload, demodulation),
-    SVGF_STRIPS (C++ multi-rank path), FRAME_GRAPH (hipGraph replay of two frames) and SVGF_4K."""
+    filterKernelBaseline / filterKernelTiled), IMAGE, VECTOR, SVGF_CORNELL (openImages upload, then svgfDenoise = the one call on the
+    GBuffer), SVGF_STRIPS (C++ multi-rank path), FRAME_GRAPH (hipGraph replay of two frames), SVGF_STREAM_4K (8-bit frames streamed
+    from and to pinned host memory through the one call; bytes of the resident frames) and SVGF_4K."""
     r = run_tests()
     sys.stdout.write(r.stdout[-6000:])
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "Fail" not in r.stdout
-    assert r.stdout.count("Passed with") >= 10
+    assert r.stdout.count("Passed with") >= 11
