@@ -549,6 +549,25 @@ def main():
     # ramp).  `value` is the steady state the metric names, so the GPU is brought there first: PRE frames of the same loop, then
     # the history is dropped, so the W + K frames that follow are the sequence they always were (frame 0 = no history).
     pre_frames = int(os.environ.get("RMD_BENCH_PRECONDITION_FRAMES", "120"))
+    # For the record, the SAME W + K frames as the process finds the GPU (what a run without the preconditioning reports: the first
+    # W + K frames of the clock ramp); reported as `cold_start`, never as `value`.
+    for f in range(args.warmup):
+        step(f)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_cold = time.perf_counter()
+    for f in range(args.warmup, nframes):
+        step(f)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t_cold = time.perf_counter() - t_cold
+    if world > 1:
+        tc = torch.tensor([t_cold], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        t_cold = float(tc.item())
+    sd.reset_history()
     t_pre = time.perf_counter()
     for f in range(pre_frames):
         step(f)
@@ -600,6 +619,8 @@ def main():
         # reprojection-miss frame per cycle through the resident sequence and against host hiccups, `value` is the wall-clock mean
         "ms_per_step_median": round(statistics.median(frame_ms), 4) if frame_ms else None,
         "mpix_s_at_median_frame": round(width * height / statistics.median(frame_ms) / 1e3, 1) if frame_ms else None,
+        "cold_start": {"ms_per_step": round(t_cold / args.steps * 1e3, 4), "value": round(width * height * args.steps / t_cold / 1e6, 1),
+                       "what": "the same W + K frames timed first, as the process finds the GPU (no preconditioning): the clock ramp of profiles/r04_clock_ramp.txt"},
         "preconditioning": {"frames": pre_frames, "ms": round(t_pre * 1e3, 1),
                             "what": "untimed frames of the same loop before the W warm-up steps (history reset afterwards): a cold GPU's "
                                     "shader clock takes ~50 ms of load to settle and the a-trous launches are clock-bound"},
