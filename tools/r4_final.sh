@@ -19,7 +19,7 @@ for form in fused chain; do
   find $OUT/prof_$form -name '*kernel_stats.csv' -exec cp {} $OUT/kernel_stats_$form.csv \;
 done
 cd $R
-python3 tools/frame_gaps.py $OUT/prof_bench --frames=128:177 > $OUT/gaps_bench.txt 2>&1 || true
+python3 tools/frame_gaps.py $OUT/prof_bench --frames=186:235 > $OUT/gaps_bench.txt 2>&1 || true
 python3 tools/frame_gaps.py $OUT/prof_bench --ramp > $OUT/ramp_bench.txt 2>&1 || true
 python3 tools/frame_gaps.py $OUT/prof_fused > $OUT/gaps_fused.txt 2>&1 || true
 python3 tools/frame_gaps.py $OUT/prof_chain > $OUT/gaps_chain.txt 2>&1 || true
