@@ -220,6 +220,41 @@ def test_gbuffer_frame_refusals(rmd, orc, cuda):
     torch.cuda.synchronize()
 
 
+def test_gbuffer_and_float_frames_alternate_on_one_context(rmd, orc, cuda):
+    """include/rmd_api.h: frames of rmd_svgf_gbuffer_frame and of rmd_svgf_context_denoise may alternate on one context; the first
+    frame after a switch starts a new history (the previous frame's nd is a plane the other path cannot name), later ones accumulate."""
+    width, height = 192, 128
+    p = rmd.default_params()
+    seq = tiled_cornell_sequence(orc, width, height, 1, (0, 0))
+    r, a, n = (dev(x) for x in seq[0])
+    den = rmd.GBufferDenoiser(width, height, params=p, debug=True)
+    color = rmd.svgf.convert_u8_to_f32(r, False, 0.0)
+    nd = rmd.svgf.convert_u8_to_f32(n, True, -1.0)
+    motion = torch.zeros((height, width, 2), dtype=torch.float32, device="cuda")
+    out = torch.empty_like(color)
+
+    def float_frame(prev_nd):
+        rmd.check(rmd.lib.rmd_svgf_context_denoise(den._ctx, C.byref(p), color.data_ptr(), nd.data_ptr(), motion.data_ptr(),
+                                                   None if prev_nd is None else prev_nd.data_ptr(), out.data_ptr(), 0, height, None))
+        torch.cuda.synchronize()
+        return int(den.t_debug[..., 3].min().item()), int(den.t_debug[..., 3].max().item())
+
+    def u8_frame():
+        den.frame(r, a, n)
+        torch.cuda.synchronize()
+        return int(den.t_debug[..., 3].min().item()), int(den.t_debug[..., 3].max().item())
+
+    assert u8_frame() == (1, 1)
+    assert u8_frame() == (2, 2)                  # static camera: every pixel reprojects onto itself
+    assert float_frame(nd) == (1, 1)             # switch: a new history although a prev_nd was handed in
+    assert float_frame(nd) == (2, 2)
+    assert float_frame(nd) == (3, 3)
+    assert u8_frame() == (1, 1)                  # and back
+    assert u8_frame() == (2, 2)
+    den.reset_history()
+    assert u8_frame() == (1, 1)
+
+
 def test_context_denoise_part_all_is_context_denoise(rmd, cuda):
     """rmd_svgf_context_denoise_part(RMD_ATROUS_ALL) is documented as 'everything in order': T + V included.  (It used to skip
     them and rotate the history over a stale frame.)  Three frames through both entry points, bit for bit."""
