@@ -87,8 +87,8 @@ int rmd_filter_baseline(rmd_gbuffer frame, rmd_filter_params params, void* strea
  * output is corrupted by a stride mismatch, SURVEY §0.2, and is not a parity target).
  * params.type selects AVERAGE (reference behaviour) or the modes the reference declares but never
  * implements (include/filter.cuh:12-19; every kernel there uses w = 1):
- *   GAUSSIAN  w = exp(-(dx^2+dy^2)/(2 sigmaSpace^2)) over the (2r+1)^2 window; radius <= 12 (the separable kernel's LDS tile;
- *             RMD_E_PARAM beyond -- AVERAGE takes any radius, as the reference does)
+ *   GAUSSIAN  w = exp(-(dx^2+dy^2)/(2 sigmaSpace^2)) over the (2r+1)^2 window; radius <= 127 (up to 12 on the separable LDS-tile
+ *             kernel, beyond on a one-thread-per-pixel kernel that states the same operations: same bits, (2r+1)^2 gathers)
  *   CROSS     GAUSSIAN x exp(-|dc|^2/(2 sigmaColor^2)) x exp(-|da|^2/(2 sigmaAlbedo^2)) x
  *             exp(-|dn|^2/(2 sigmaNormal^2)) with c = the level's input plane, a / n = frame.albedo /
  *             frame.normal (0..255 units; a term with sigma <= 0 or a NULL plane is dropped)

@@ -383,6 +383,45 @@ __global__ __launch_bounds__(256) void gaussian_separable_kernel(GaussArgs a)
     }
 }
 
+// Radii 13 .. 127: one thread per pixel, the SAME operations in the same order (per window row the horizontal sum over the in-frame dx,
+// then the vertical accumulation over the in-frame dy, fused multiply-adds; hw, vw plain sums; one product, three divisions), so the
+// same bits as the separable kernel would give -- without its LDS tile, at (2r+1)^2 gathers per pixel.  AVERAGE takes any radius (the
+// reference's loop does, src/filter.cu:34); this keeps GAUSSIAN from refusing what AVERAGE accepts.
+constexpr int kGaussDirectMaxRadius = 127;
+struct GaussDirectArgs {
+    const uchar4* in; uchar4* out;
+    int W, H, radius;
+    float g[kGaussDirectMaxRadius + 1];
+};
+
+__global__ __launch_bounds__(256) void gaussian_direct_kernel(GaussDirectArgs a)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.W || y >= a.H) return;
+    const int R = a.radius;
+    float hw = 0.0f;
+    for (int dx = -R; dx <= R; ++dx)
+        if (x + dx >= 0 && x + dx < a.W) hw += a.g[dx < 0 ? -dx : dx];
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f, vw = 0.0f;
+    for (int dy = -R; dy <= R; ++dy) {
+        const int ty = y + dy;
+        if (ty < 0 || ty >= a.H) continue;
+        float hr = 0.0f, hg = 0.0f, hb = 0.0f;
+        for (int dx = -R; dx <= R; ++dx) {
+            const int tx = x + dx;
+            if (tx < 0 || tx >= a.W) continue;
+            const uchar4 c = a.in[(size_t)ty * a.W + tx];
+            const float w = a.g[dx < 0 ? -dx : dx];
+            hr = __builtin_fmaf(w, (float)c.x, hr); hg = __builtin_fmaf(w, (float)c.y, hg); hb = __builtin_fmaf(w, (float)c.z, hb);
+        }
+        const float w = a.g[dy < 0 ? -dy : dy];
+        sr = __builtin_fmaf(w, hr, sr); sg = __builtin_fmaf(w, hg, sg); sb = __builtin_fmaf(w, hb, sb); vw += w;
+    }
+    const float sw = hw * vw;
+    a.out[(size_t)y * a.W + x] = make_uchar4((unsigned char)(sr / sw), (unsigned char)(sg / sw), (unsigned char)(sb / sw), 0);
+}
+
 template <int RT>
 static void launch_gaussian(const GaussArgs& a, hipStream_t stream)
 {
@@ -399,8 +438,8 @@ int run_weighted_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStr
         return fail(RMD_E_PARAM, "rmd_filter_tiled: WAVELET level %d + depth %d outside [0,12]", p.level, p.depth);
     if (p.type == RMD_FILTER_GAUSSIAN && !(p.sigmaSpace > 0.0f))
         return fail(RMD_E_PARAM, "rmd_filter_tiled: GAUSSIAN needs sigmaSpace > 0");
-    if (p.type == RMD_FILTER_GAUSSIAN && p.radius > kGaussMaxRadius)
-        return fail(RMD_E_PARAM, "rmd_filter_tiled: GAUSSIAN radius %d > %d (the separable kernel's LDS tile)", p.radius, kGaussMaxRadius);
+    if (p.type == RMD_FILTER_GAUSSIAN && p.radius > kGaussDirectMaxRadius)
+        return fail(RMD_E_PARAM, "rmd_filter_tiled: GAUSSIAN radius %d > %d", p.radius, kGaussDirectMaxRadius);
     const int W = f.shape.x, H = f.shape.y;
     for (int level = 0; level < p.depth; ++level) {
         WeightedArgs a;
@@ -413,6 +452,14 @@ int run_weighted_levels(const rmd_gbuffer& f, const rmd_filter_params& p, hipStr
         a.step = p.type == RMD_FILTER_WAVELET ? (1 << (p.level + level)) : 1;
         a.inv2s_space = inv2s(p.sigmaSpace); a.inv2s_color = inv2s(p.sigmaColor);
         a.inv2s_albedo = inv2s(p.sigmaAlbedo); a.inv2s_normal = inv2s(p.sigmaNormal);
+        if (p.type == RMD_FILTER_GAUSSIAN && a.radius > kGaussMaxRadius) {          // beyond the separable kernel's LDS tile
+            GaussDirectArgs gd;
+            gd.in = a.in; gd.out = a.out; gd.W = W; gd.H = H; gd.radius = a.radius;
+            for (int d = 0; d <= kGaussDirectMaxRadius; ++d) gd.g[d] = expf(-(float)(d * d) * a.inv2s_space);
+            hipLaunchKernelGGL(gaussian_direct_kernel, dim3((W + 63) / 64, (H + 3) / 4), dim3(256), 0, stream, gd);
+            RMD_LAUNCH_CHECK("gaussian_direct_kernel");
+            continue;
+        }
         if (p.type == RMD_FILTER_GAUSSIAN) {
             GaussArgs ga;
             ga.in = a.in; ga.out = a.out; ga.W = W; ga.H = H; ga.radius = a.radius;

@@ -192,7 +192,7 @@ def test_ragged_shapes_and_missing_planes(rmd, orc, cuda, shape):
     for level in (3, 5):     # spacings 8 (the lattice tile), 16, 32 and 32, 64, 128 (the gather kernel)
         pw = make_params(rmd, rmd.FilterParams.WAVELET, level=level, depth=3)
         assert_close_u8(gpu_run(rmd, img, pw, nrm, alb), orc.weighted_filter(img, pw, nrm, alb))
-    for radius in (0, 1, 3, 7, 12):          # GAUSSIAN: every radius the separable kernel takes (1..4 unrolled, the rest at run time)
+    for radius in (0, 1, 3, 7, 12, 13, 20, 40):   # GAUSSIAN: the separable kernel (1..4 unrolled, up to 12 at run time), beyond it the direct kernel
         pg = make_params(rmd, rmd.FilterParams.GAUSSIAN, radius=radius, sigmaSpace=0.8 + radius)
         assert_close_u8(gpu_run(rmd, img, pg), orc.weighted_filter(img, pg), exact=True)
 
@@ -252,5 +252,5 @@ def test_parameter_errors(rmd, cuda):
         rmd.filterKernelTiled(g, make_params(rmd, rmd.FilterParams.WAVELET, level=12))
     assert e.value.code == -3
     with pytest.raises(rmd.RmdError) as e:
-        rmd.filterKernelTiled(g, make_params(rmd, rmd.FilterParams.GAUSSIAN, radius=13))
+        rmd.filterKernelTiled(g, make_params(rmd, rmd.FilterParams.GAUSSIAN, radius=128))
     assert e.value.code == -3
