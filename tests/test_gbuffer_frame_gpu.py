@@ -255,6 +255,40 @@ def test_gbuffer_and_float_frames_alternate_on_one_context(rmd, orc, cuda):
     assert u8_frame() == (1, 1)
 
 
+def test_gbuffer_frames_replayed_from_a_graph_equal_eager_frames(rmd, orc, cuda):
+    """The one-call path under rmd_graph_*: two frames (the context's history and nd planes ping-pong) captured on a side stream
+    behind two eager ones (the first call allocates the context's nd planes) and replayed give the eager sequence's bytes."""
+    width, height = 320, 200
+    p = rmd.default_params()
+    seq = tiled_cornell_sequence(orc, width, height, 2, (1, 0))
+    fa, fb = (tuple(dev(x) for x in fr) for fr in seq)
+    motion = torch.zeros((height, width, 2), dtype=torch.float32, device="cuda")
+    motion[..., 0] = -1.0
+    eager = rmd.GBufferDenoiser(width, height, params=p)
+    want = torch.empty_like(fa[0])
+    for _ in range(4):                                   # A B | A B A B A B
+        eager.frame(*fa, want, motion)
+        eager.frame(*fb, want, motion)
+    torch.cuda.synchronize()
+    den = rmd.GBufferDenoiser(width, height, params=p)
+    got = torch.zeros_like(fa[0])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        den.frame(*fa, got, motion)
+        den.frame(*fb, got, motion)
+        side.synchronize()
+    with rmd.capture(side) as g:
+        den.frame(*fa, got, motion)
+        den.frame(*fb, got, motion)
+    side.synchronize()
+    assert not torch.equal(got, want)                    # the captured frames have not run
+    for _ in range(3):
+        g.launch()
+    side.synchronize()
+    assert torch.equal(got, want), f"{(got != want).sum().item()} bytes differ"
+    g.destroy()
+
+
 def test_context_denoise_part_all_is_context_denoise(rmd, cuda):
     """rmd_svgf_context_denoise_part(RMD_ATROUS_ALL) is documented as 'everything in order': T + V included.  (It used to skip
     them and rotate the history over a stale frame.)  Three frames through both entry points, bit for bit."""
