@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 ATROUS_BYTES_PER_PX = 48       # per iteration: color 16 + nd 16 read, color 16 written
+TV_BYTES_PER_PX = 106          # T + V in one launch: 81 read + 25 written (measure_roofline)
 FULL_BYTES_PER_PX = 424        # T 120 + V 64 + 5 x 48, every pass priced on its own
 MOVED_BYTES_PER_PX = 346       # what rmd_svgf_frame moves: T+V 81 read (color 16, nd 16, motion 8, prev_nd 16, hist_color 16, hist_moments 8,
                                # hist_len 1) + 25 written (v_color 16, t_moments 8, t_len 1; V's windows are recomputed in the T
@@ -145,10 +146,16 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps, whole
     it_reach = rmd.svgf.frame_iteration_reach(p)     # rows beyond the strip each iteration is computed on (rmd_svgf_frame)
     H = den.height
     sums, launch_px = [0.0] * n, [0] * n
+    tv_ms = []
     for rep in range(reps + 2):
         color, nd, motion = frames[rep % len(frames)]
         desc = den.describe(color, nd, motion, out)
+        rmd.check(rmd.lib.rmd_timer_start(timer, None))
         rmd.check(rmd.lib.rmd_svgf_frame_tv(C.byref(desc), C.byref(p), row0, row1, None))
+        rmd.check(rmd.lib.rmd_timer_stop(timer, None))
+        rmd.check(rmd.lib.rmd_timer_elapsed_ms(timer, C.byref(ms)))
+        if rep >= 2:
+            tv_ms.append(ms.value)
         src, pp = den.v_color, 0
         for it in range(n):
             if it == n - 1:
@@ -175,19 +182,20 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps, whole
     achieved = ATROUS_BYTES_PER_PX * px / (avg_ms * 1e-3) / 1e9          # bytes of the average launch / the average launch time
     # PMC-measured HBM bytes per launch, if a rocprofv3 --pmc pass of this command was reduced
     # into profiles/ (tools/pmc_traffic.py); null otherwise.
-    traffic, valu = None, None
+    traffic, valu, tv_traffic = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     # (the counter passes were taken on whole 3840x2160 launches: they say nothing about a strip's launches)
     if whole_frame_4k and os.path.exists(tpath):
         try:
             pmc = json.load(open(tpath))
             traffic = pmc.get("atrous_hbm_bytes_per_launch")
+            tv_traffic = (pmc.get("temporal_variance") or {}).get("hbm_bytes_per_launch")
             vi = pmc.get("valu_issue")
             if vi:   # the bound the kernel actually sits on (PMC passes of the same kernels, tools/pmc_passes.sh)
                 valu = {"busy_frac": vi["avg_valu_busy_frac"], "resident_waves_per_simd": vi["avg_resident_waves_per_simd"],
                         "max_waves_per_simd": 3, "source": "profiles/pmc_traffic.json (rocprofv3 --pmc)"}
         except Exception:
-            traffic, valu = None, None
+            traffic, valu, tv_traffic = None, None, None
     return {
         "bound": "hbm", "kernel": "atrous_stream_kernel<S,2> (one a-trous iteration, avg over S=1,2,4,8,16)",
         "note": "priced against HBM as BASELINE.json asks; the kernel is VALU-issue bound (DESIGN.md §4)",
@@ -200,7 +208,19 @@ def measure_roofline(rmd, torch, den, frames, width, rows_out, plan, reps, whole
         "per_iteration_ms": [round(v, 5) for v in per_iter],
         "atrous_x5_ms": round(sum(per_iter), 5),
         "atrous_x5_mpix_s": round(width * rows_out / (sum(per_iter) * 1e-3) / 1e6, 1),
+        # the frame's other kernel, HBM-bound: T + V in one launch, 106 B/px algorithmic (81 read: color 16, nd 16, motion 8, prev_nd 16,
+        # hist_color 16, hist_moments 8, hist_len 1; 25 written: v_color 16, t_moments 8, t_len 1); MEDIAN launch (the frames that
+        # restart the history run V everywhere), same timing method; rows = the strip's T rows on N > 1
+        "temporal_variance": tv_roofline(tv_ms, width * (min(H, row1 + rmd.svgf.frame_reach(p)[3]) - max(0, row0 - rmd.svgf.frame_reach(p)[3])), tv_traffic),
     }
+
+
+def tv_roofline(tv_ms, px, traffic):
+    med = statistics.median(tv_ms)
+    achieved = TV_BYTES_PER_PX * px / (med * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "svgf_temporal_variance_kernel (T + V, one launch)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "algorithmic_bytes_per_launch": int(TV_BYTES_PER_PX * px),
+            "median_launch_ms": round(med, 5)}
 
 
 def other_size(rmd, torch, width, height, p, frames=16, warm=4):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/pmc_traffic.py <pmc dir> <out.json> [shader GHz] -- HBM bytes per launch and VALU issue figures of the
+"""tools/pmc_traffic.py <pmc dir> <out.json> [shader GHz] [pmc_frame dir] -- HBM bytes per launch and VALU issue figures of the
 a-trous kernels from the rocprofv3 --pmc passes of tools/pmc_passes.sh (one counter set per pass).
 Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE and WRITE_SIZE are in
 KiB; FETCH_SIZE reports exactly half of the bytes of a wide (16 B/lane) coalesced read stream, so it is doubled;
@@ -52,6 +52,25 @@ if valu:
         "avg_resident_waves_per_simd": round(mean([x["resident_waves_per_simd"] for x in valu.values()]), 2),
         "method": "SQ_ACTIVE_INST_VALU (quad-cycles) x4 / (launch duration in the same pass x the in-kernel shader clock x 1024 SIMDs); "
                   "SQ_WAVE_CYCLES (quad-cycles) x4 / the same cycles / 1024 SIMDs; 3 waves per SIMD is the maximum for this kernel"}
+# T+V (HBM-bound): FETCH_SIZE / WRITE_SIZE of the frame loop (tools/pmc_frame.sh), MEDIANS over the launches (the frames without
+# history run V everywhere); optional 4th argument = that directory
+if len(sys.argv) > 4:
+    tv = collections.defaultdict(list)
+    tvdur = []
+    for f in sorted(glob.glob(os.path.join(sys.argv[4], "*_counter_collection.csv"))):
+        for row in csv.DictReader(open(f)):
+            if "svgf_temporal_variance_kernel" in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                tv[row["Counter_Name"]].append(float(row["Counter_Value"]))
+                if row["Counter_Name"] == "WRITE_SIZE":
+                    tvdur.append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
+    if tv["FETCH_SIZE"] and tv["WRITE_SIZE"]:
+        med = lambda v: sorted(v)[len(v) // 2]  # noqa: E731
+        doc["temporal_variance"] = {
+            "FETCH_SIZE_KiB_median": med(tv["FETCH_SIZE"]), "WRITE_SIZE_KiB_median": med(tv["WRITE_SIZE"]),
+            "hbm_bytes_per_launch": int((2.0 * med(tv["FETCH_SIZE"]) + med(tv["WRITE_SIZE"])) * 1024),
+            "launch_us_in_the_write_pass_median": round(med(tvdur), 1),
+            "algorithmic_bytes_per_launch": 106 * 3840 * 2160,
+            "note": "the x2 of FETCH_SIZE is calibrated for 16 B/lane reads (64 of this kernel's 81 read bytes per pixel); medians of the frame loop"}
 json.dump(doc, open(out, "w"), indent=1)
 print("atrous_hbm_bytes_per_launch", avg, "algorithmic", 48 * 3840 * 2160)
 if valu:

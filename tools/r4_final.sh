@@ -28,7 +28,7 @@ tools/pmc_passes.sh $OUT/pmc > $OUT/pmc_passes.log 2>&1 || true
 tools/pmc_frame.sh $OUT/pmc_frame > $OUT/pmc_frame.txt 2>&1 || true
 RMD_LIB_PATH=$R/build/variants/librmd_trace.so timeout -k 10 200 python3 tools/atrous_trace.py > $OUT/trace.txt 2>&1 || true
 grep "shader clock\|kernel span" $OUT/trace.txt || true
-python3 tools/pmc_traffic.py $OUT/pmc $OUT/pmc_traffic.json 2.04 > $OUT/pmc_traffic.txt 2>&1 || true
+python3 tools/pmc_traffic.py $OUT/pmc $OUT/pmc_traffic.json 2.04 $OUT/pmc_frame > $OUT/pmc_traffic.txt 2>&1 || true
 python3 tools/pmc_summary.py $OUT/pmc > $OUT/pmc_atrous.txt 2>&1 || true
 cd /tmp
 for nt in 1 0; do
