@@ -276,6 +276,32 @@ __device__ __forceinline__ void tap_pair(Acc<f2>& s, const Center<f2>& k, const 
     tap_accumulate<f2>(s, exp2_(e), t);
 }
 
+// The wave whose centres ALL have a zero normal (the background of the Cornell planes: 65 % of their pixels): Appendix A.A.2 leaves
+// w_n = 1 for a zero tap normal and 0 for any other, so there is no cosine and no logarithm to take -- the zero-aware form
+// computes clamp01(0 . n_t + 1 * ft) = ft and then sigma_n * log2(ft) + e0, which is e0 exactly for ft = 1 (log2 1 = 0, and
+// fma(sigma_n, 0, e0) rounds nothing) and -inf for ft = 0.  Same bits, without 5 packed + 1 plain + 2 transcendental
+// instructions of the 27 slot-equivalents a zero-aware pair tap costs.
+__device__ __forceinline__ void tap_pair_zero_centres(Acc<f2>& s, const Center<f2>& k, const CenterAux& xa, const CenterAux& xb,
+                                                      const Tap& t, float e0A, float e0B, int adx, int adyA, int adyB)
+{
+    const bool tz = tap_is_zero(t.n) != 0.0f;
+    f2 e = f2{ tz ? e0A : kNegInf, tz ? e0B : kNegInf };
+    const f2 dz = k.z - f2{ t.n.w, t.n.w }, dl = k.lum - f2{ t.c.x, t.c.x };
+    if (adx | adyA) e.x = fma_(-fabsf(dz.x), xa.iz[len_class(adx, adyA)], e.x);
+    if (adx | adyB) e.y = fma_(-fabsf(dz.y), xb.iz[len_class(adx, adyB)], e.y);
+    e.x = fma_(-fabsf(dl.x), k.il.x, e.x);
+    e.y = fma_(-fabsf(dl.y), k.il.y, e.y);
+    tap_accumulate<f2>(s, exp2_(e), t);
+}
+__device__ __forceinline__ void tap_single_zero_centre(Acc<float>& s, const Center<float>& k, const CenterAux& x, const Tap& t,
+                                                       float e0, int adx, int ady)
+{
+    float e = tap_is_zero(t.n) != 0.0f ? e0 : kNegInf;
+    if (adx | ady) e = fma_(-fabsf(k.z - t.n.w), x.iz[len_class(adx, ady)], e);
+    e = fma_(-fabsf(k.lum - t.c.x), k.il, e);
+    tap_accumulate<float>(s, exp2_(e), t);
+}
+
 // A.A.3.  c = the centre in (lum, r, g, var) form.
 __device__ __forceinline__ float4 finish(float sw, float sl, float sr, float sg, float sv, const float4 c)
 {
@@ -698,6 +724,7 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
         }
         // a wave takes the cheaper path when none of its centres has a zero normal
         const bool any_zero = __builtin_amdgcn_ballot_w64(xA.zero || xB.zero) != 0ull;
+        const bool all_zero = __builtin_amdgcn_ballot_w64(!(xA.zero && xB.zero)) == 0ull;       // every centre of the wave: no cosine to take
         float sn;                                                      // sigma_n in a VGPR (see tap_pair)
         asm volatile("v_mov_b32 %0, %1" : "=v"(sn) : "s"(a.sigma_n));
 
@@ -715,8 +742,9 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
                 t[q].n = lds_f4(lds, C::PLANE_BYTES + off);
             }
         };
-        auto taps = [&](auto zero_aware) {
-            constexpr bool ZA = decltype(zero_aware)::value;
+        auto taps = [&](auto zero_mode) {             // 0: no centre of the wave has a zero normal | 1: some have | 2: all have
+            constexpr int ZM = decltype(zero_mode)::value;
+            constexpr bool ZA = ZM != 0;
             // per-output order stays dx outer / dy inner: A sees rows 0..4 as dy=-2..2, B rows 1..5
             auto weigh_grp = [&](const int grp, const Tap (&t)[GR]) {
                 const int dxi = grp / (6 / GR), tr0 = (grp % (6 / GR)) * GR;
@@ -735,9 +763,15 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
                     // log2 k of the tap, or -inf for a tap outside the frame (w becomes exactly 0)
                     const float e0A = valid ? kLogB3[adx] + kLogB3[adyA] : kNegInf;
                     const float e0B = valid ? kLogB3[adx] + kLogB3[adyB] : kNegInf;
-                    if (tr == 0)      tap_single<ZA>(sA, kA, xA, t[q], e0A, adx, adyA, sn);
-                    else if (tr == 5) tap_single<ZA>(sB, kB, xB, t[q], e0B, adx, adyB, sn);
-                    else              tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0A, e0B, adx, adyA, adyB, sn);
+                    if constexpr (ZM == 2) {
+                        if (tr == 0)      tap_single_zero_centre(sA, kA, xA, t[q], e0A, adx, adyA);
+                        else if (tr == 5) tap_single_zero_centre(sB, kB, xB, t[q], e0B, adx, adyB);
+                        else              tap_pair_zero_centres(sAB, kAB, xA, xB, t[q], e0A, e0B, adx, adyA, adyB);
+                    } else {
+                        if (tr == 0)      tap_single<ZA>(sA, kA, xA, t[q], e0A, adx, adyA, sn);
+                        else if (tr == 5) tap_single<ZA>(sB, kB, xB, t[q], e0B, adx, adyB, sn);
+                        else              tap_pair<ZA>(sAB, kAB, xA, xB, t[q], e0A, e0B, adx, adyA, adyB, sn);
+                    }
                 }
             };
             Tap t0[GR], t1[GR];
@@ -758,7 +792,9 @@ __device__ __forceinline__ void atrous_stream_body(const AtrousArgs& a, unsigned
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (any_zero) taps(std::true_type{}); else taps(std::false_type{});
+        if (all_zero)      taps(std::integral_constant<int, 2>{});
+        else if (any_zero) taps(std::integral_constant<int, 1>{});
+        else               taps(std::integral_constant<int, 0>{});
 
         // Per-pixel sums = (row only this pixel taps: dy=-2 for role A, dy=+2 for role B) + (the four
         // rows shared with its partner), each summed dx outer / dy inner.  The direct kernel groups
