@@ -116,26 +116,63 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
     if (a.tile_flags && threadIdx.x == 0) a.tile_flags[(size_t)tile_y * a.tiles_x + tile_x] = (unsigned char)(any != 0);
     if (!any) return;
 
-    // ---- T's output and nd on the tile + halo into LDS -- only where a 7x7 window of a short-history pixel can reach: the
-    // bounding box of those pixels + 3 (a band along a frame edge needs ~70 halo pixels, not 444).  Own pixel from
-    // registers, halo pixels recomputed.
+    // ---- T's output and nd on the tile + halo into LDS.  Own pixel from registers; the halo pixels are RECOMPUTED, and only those
+    // some 7x7 window of a short-history pixel reaches (Chebyshev distance <= 3 to such a pixel), dealt out to the threads without
+    // holes: a silhouette that crosses the tile needs ~100 of the 444 halo pixels, and as the bounding box of round 3 they were spread
+    // over two rounds of the recomputation (three dependent memory round trips each) in which most lanes idled.
+    // Everything that decides WHICH cells is wave-uniform (the four row masks of the tile): per staged row ry the 70-bit mask of the
+    // needed cells (need_lo: columns 0..63 of the staged region, need_hi: 64..69) and the running count, in scalar registers.
     const unsigned long long m0 = wave_mask[0], m1 = wave_mask[1], m2 = wave_mask[2], m3 = wave_mask[3];
-    const unsigned long long cols = m0 | m1 | m2 | m3;
-    const int bx0 = __builtin_ctzll(cols) - kVR, bx1 = 63 - __builtin_clzll(cols) + kVR;            // tile coordinates, inclusive
-    const int by0 = (m0 ? 0 : m1 ? 1 : m2 ? 2 : 3) - kVR, by1 = (m3 ? 3 : m2 ? 2 : m1 ? 1 : 0) + kVR;
+    unsigned long long need_lo[kVH];
+    unsigned need_hi[kVH];
+    int before[kVH + 1];
+    before[0] = 0;
+#pragma unroll
+    for (int ry = 0; ry < kVH; ++ry) {
+        // tile rows r with |r - (ry - 3)| <= 3, i.e. ry - 6 <= r <= ry
+        unsigned long long rows = 0ull;
+        if (ry <= 6) rows |= m0;
+        if (ry >= 1 && ry <= 7) rows |= m1;
+        if (ry >= 2 && ry <= 8) rows |= m2;
+        if (ry >= 3) rows |= m3;
+        // a pixel in tile column c reaches staged columns c .. c + 6
+        unsigned long long lo = rows;
+        unsigned hi = 0u;
+#pragma unroll
+        for (int d = 1; d <= 2 * kVR; ++d) { lo |= rows << d; hi |= (unsigned)(rows >> (64 - d)); }
+        if (ry >= kVR && ry < kVR + 4) { lo &= (1ull << kVR) - 1ull; hi &= ~((1u << kVR) - 1u); }   // the tile itself: columns 3 .. 66
+        // pixels outside the frame are never tapped (A.V skips them); neither are rows outside T's range: V's rows lie
+        // at least 3 rows inside it wherever the frame goes on (launch_temporal_variance)
+        const int ty = y0 - kVR + ry;
+        if (ty < a.row0 || ty >= a.row1) { lo = 0ull; hi = 0u; }
+        if (x0 == 0) lo &= ~((1ull << kVR) - 1ull);                                     // staged columns 0 .. 2 are left of the frame
+        const int cols_in = g.W - (x0 - kVR);                                           // staged columns < cols_in are inside the frame
+        if (cols_in < kVW) { lo &= cols_in >= 64 ? ~0ull : ((1ull << cols_in) - 1ull); hi &= cols_in > 64 ? ((1u << (cols_in - 64)) - 1u) : 0u; }
+        need_lo[ry] = lo; need_hi[ry] = hi & 0x3fu;
+        before[ry + 1] = before[ry] + __builtin_popcountll(lo) + __builtin_popcount(hi & 0x3fu);
+    }
     if (active) {
         scr[ly + kVR][lx + kVR] = tc.x; scg[ly + kVR][lx + kVR] = tc.y; scb[ly + kVR][lx + kVR] = tc.z;
         if constexpr (IN8) sn[ly + kVR][lx + kVR] = nd_own;
         else sn[ly + kVR][lx + kVR] = a.nd[pix_index(g, x, y)];
     }
-    for (int q = threadIdx.x; q < kVW * kVH; q += 256) {
-        const int ry = q / kVW, rx = q - ry * kVW;
-        if (ry >= kVR && ry < kVR + 4 && rx >= kVR && rx < kVR + 64) continue;            // the tile itself
-        if (rx - kVR < bx0 || rx - kVR > bx1 || ry - kVR < by0 || ry - kVR > by1) continue; // no window reaches it
+    for (int i = threadIdx.x; i < before[kVH]; i += 256) {
+        // the i-th needed cell: its row by the running counts, then the (i - before[ry])-th set bit of the row's mask
+        int ry = 0, j = i;
+        unsigned long long lo = need_lo[0];
+        unsigned hi = need_hi[0];
+#pragma unroll
+        for (int r = 1; r < kVH; ++r)
+            if (i >= before[r]) { ry = r; j = i - before[r]; lo = need_lo[r]; hi = need_hi[r]; }
+        int rx = 0;                                                                      // binary search: set bits below rx <= j
+#pragma unroll
+        for (int step = 64; step >= 1; step >>= 1) {
+            const int cand = rx + step;
+            const int below = cand >= 64 ? __builtin_popcountll(lo) + __builtin_popcount(hi & ((1u << min(cand - 64, 31)) - 1u))
+                                         : __builtin_popcountll(lo & ((1ull << cand) - 1ull));
+            if (cand < kVW && below <= j) rx = cand;
+        }
         const int tx = x0 - kVR + rx, ty = y0 - kVR + ry;
-        // pixels outside the frame are never tapped (A.V skips them); neither are rows outside T's range: V's rows lie
-        // at least 3 rows inside it wherever the frame goes on (launch_temporal_variance)
-        if (tx < 0 || tx >= g.W || ty < a.row0 || ty >= a.row1) continue;
         float4 hc, hn;
         float2 mom;
         int4 dbg;
