@@ -156,21 +156,31 @@ __global__ __launch_bounds__(256) void svgf_temporal_variance_kernel(TemporalArg
         if constexpr (IN8) sn[ly + kVR][lx + kVR] = nd_own;
         else sn[ly + kVR][lx + kVR] = a.nd[pix_index(g, x, y)];
     }
+    constexpr int kRing = kVW * kVH - 64 * 4;                    // 444: the whole halo ring
+    const bool whole_ring = before[kVH] == kRing;                // frames without history: every tile, every cell -- no need to search
     for (int i = threadIdx.x; i < before[kVH]; i += 256) {
-        // the i-th needed cell: its row by the running counts, then the (i - before[ry])-th set bit of the row's mask
-        int ry = 0, j = i;
-        unsigned long long lo = need_lo[0];
-        unsigned hi = need_hi[0];
+        int ry, rx;
+        if (whole_ring) {                                        // (workgroup-uniform) rows 0..2 | the six side columns of rows 3..6 | rows 7..9
+            if (i < kVR * kVW)               { ry = i / kVW; rx = i - ry * kVW; }
+            else if (i < kVR * kVW + 4 * 6)  { const int j = i - kVR * kVW; ry = kVR + j / 6; const int c = j - (j / 6) * 6; rx = c < kVR ? c : 64 + c; }
+            else                             { const int j = i - kVR * kVW - 4 * 6; ry = kVR + 4 + j / kVW; rx = j - (j / kVW) * kVW; }
+        } else {
+            // the i-th needed cell: its row by the running counts, then the (i - before[ry])-th set bit of the row's mask
+            int j = i;
+            ry = 0;
+            unsigned long long lo = need_lo[0];
+            unsigned hi = need_hi[0];
 #pragma unroll
-        for (int r = 1; r < kVH; ++r)
-            if (i >= before[r]) { ry = r; j = i - before[r]; lo = need_lo[r]; hi = need_hi[r]; }
-        int rx = 0;                                                                      // binary search: set bits below rx <= j
+            for (int r = 1; r < kVH; ++r)
+                if (i >= before[r]) { ry = r; j = i - before[r]; lo = need_lo[r]; hi = need_hi[r]; }
+            rx = 0;                                                                      // binary search: set bits below rx <= j
 #pragma unroll
-        for (int step = 64; step >= 1; step >>= 1) {
-            const int cand = rx + step;
-            const int below = cand >= 64 ? __builtin_popcountll(lo) + __builtin_popcount(hi & ((1u << min(cand - 64, 31)) - 1u))
-                                         : __builtin_popcountll(lo & ((1ull << cand) - 1ull));
-            if (cand < kVW && below <= j) rx = cand;
+            for (int step = 64; step >= 1; step >>= 1) {
+                const int cand = rx + step;
+                const int below = cand >= 64 ? __builtin_popcountll(lo) + __builtin_popcount(hi & ((1u << min(cand - 64, 31)) - 1u))
+                                             : __builtin_popcountll(lo & ((1ull << cand) - 1ull));
+                if (cand < kVW && below <= j) rx = cand;
+            }
         }
         const int tx = x0 - kVR + rx, ty = y0 - kVR + ry;
         float4 hc, hn;

@@ -61,3 +61,25 @@ def test_needed_halo_cells_are_dealt_out_exactly_once():
         y0=random.choice([0,4,100]); row0=random.choice([0,y0-2 if y0>=2 else 0]); row1=random.choice([y0+4,y0+5,y0+8,2160])
         c=plan(m,x0,W,y0,row0,row1); tr=truth(m,x0,W,y0,row0,row1)
         assert len(c)==len(set(c)) and set(c)==tr, (t, len(c), len(tr))
+
+
+def test_whole_ring_shortcut_enumerates_the_ring():
+    """Frames without history flag every tile and need every halo cell: the kernel then maps thread i straight to the i-th cell of the
+    ring (rows 0..2, the six side columns of rows 3..6, rows 7..9) instead of searching; replayed here."""
+    cells = set()
+    for i in range(kVW * kVH - 256):
+        if i < kVR * kVW:
+            ry = i // kVW
+            rx = i - ry * kVW
+        elif i < kVR * kVW + 24:
+            j = i - kVR * kVW
+            ry = kVR + j // 6
+            c = j - (j // 6) * 6
+            rx = c if c < kVR else 64 + c
+        else:
+            j = i - kVR * kVW - 24
+            ry = kVR + 4 + j // kVW
+            rx = j - (j // kVW) * kVW
+        assert not (3 <= ry < 7 and 3 <= rx < 67)
+        cells.add((ry, rx))
+    assert len(cells) == 444 and all(0 <= ry < kVH and 0 <= rx < kVW for ry, rx in cells)
